@@ -1,0 +1,188 @@
+#!/usr/bin/env python3
+"""Benchmark of the multi-start travel-time sweep (the hot path of
+serial_new/sweep-tt-multistart.c) on MI355X.
+
+  python bench.py --gpus 1 --steps K --warmup W
+  python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+Workload (BASELINE.json metric config): synthetic 241x241x51 velocity volume
+(the real model is absent from the reference tree), the reference's default
+818-offset star (docs/818-FS.txt, serial_new/Makefile:15) and the 24 start points
+of docs/start-24-241-241-51.txt.  One "step" = one complete multi-start solve:
+initialise every travel-time box on the device (all INFINITY, start 0), relax to
+convergence, and - for N > 1 - gather all boxes on rank 0 over RCCL.  The starts
+are sharded round-robin over the N ranks (strong scaling: the 24 starts are the
+fixed total work); inputs are resident in HBM when the timed region starts.
+
+metric: Mcells*sweeps/s = cells x (sum over starts of full-grid relaxation passes
+executed) / wall seconds / 1e6.  A pass relaxes every cell against the whole
+forward star once; passes of different schedules are the same amount of work but
+not the same progress, so ms_per_step (time to the converged solution) is the
+number to compare across schedules and against the CPU.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0               # MI355X_MICROARCH.md: 8.0 TB/s spec
+VALU_PEAK_TLANEOPS = 78.6           # 256 CU x 4 SIMD x 32 lanes/clk x 2.4 GHz (SIMD-32)
+BYTES_PER_CELL_SWEEP = 12           # read v, read tt, write tt
+LANEOPS_PER_RELAX = 4               # add, mul, add, min
+
+
+def cpu_baseline(P, v, offs, start, sweeps=2):
+    """The CPU restatement of serial_new (oracle/, kind "port") timed on this
+    host: `sweeps` reference-order passes of one start from the initial state."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import oracle as O
+    O.build()
+    fs = O.make_star(offs)
+    tt = O.tt_init(v.shape, start)
+    t0 = time.perf_counter()
+    for _ in range(sweeps):
+        O.sweep(v, tt, fs, start)
+    dt = time.perf_counter() - t0
+    return {"value": v.size * sweeps / dt / 1e6, "unit": "Mcells*sweeps/s", "cores": 1,
+            "kind": "port", "seconds": round(dt, 2),
+            "sample": f"{sweeps} reference-order passes of start 0 on the same grid/star "
+                      f"(single thread, gcc -O3; host has {os.cpu_count()} logical cores)"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--grid", default="241,241,51")
+    ap.add_argument("--star", default="818")
+    ap.add_argument("--starts", default="24")
+    ap.add_argument("--kernel", type=int, default=0)
+    ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
+    args = ap.parse_args()
+
+    import torch
+    import ttsweep_pkg
+    P = ttsweep_pkg.load()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+
+    nx, ny, nz = map(int, args.grid.split(","))
+    cells = nx * ny * nz
+    offs = P.inputs.read_triples(P.inputs.star_path(args.star))
+    fs = P.inputs.make_fs(offs)
+    starts = P.inputs.read_triples(P.inputs.starts_path(args.starts))
+    if (nx, ny, nz) != (241, 241, 51):
+        starts = P.inputs.scaled_starts(starts, nx, ny, nz)
+        v_dev = P.inputs.velocity_model_device(nx, ny, nz, 20160507, dev)
+        v_host = None
+    else:
+        v_host = P.inputs.velocity_model(nx, ny, nz, 20160507)
+        v_dev = torch.from_numpy(v_host).to(dev)
+    nstart = len(starts)
+    mine = P.multistart.shard_starts(nstart, world, rank)
+    my_starts = starts[mine]
+
+    sol = P.TravelTimeSolver((nx, ny, nz), fs, device=local_rank)
+    if args.kernel:
+        sol.set_option(P.OPT_KERNEL, args.kernel)
+    sol.set_velocity(v_dev)
+    tt = torch.empty((len(mine), nx, ny, nz), dtype=torch.float32, device=dev)
+
+    def step():
+        sol.solve_device(my_starts, tt, init=True)
+        return P.multistart.gather_boxes(tt, nstart, dist, dst=0)
+
+    def fence():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    t0 = time.perf_counter()
+    sweeps_local = 0
+    for _ in range(args.steps):
+        step()
+        sweeps_local += sol.stats()["sweeps_total"]
+    fence()
+    dt = time.perf_counter() - t0
+
+    # max over ranks of the elapsed time, sum over ranks of the passes executed
+    agg = torch.tensor([dt, float(sweeps_local)], dtype=torch.float64, device=dev)
+    if dist is not None:
+        tmax = agg[:1].clone()
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        ssum = agg[1:].clone()
+        dist.all_reduce(ssum, op=dist.ReduceOp.SUM)
+        dt, sweeps_all = float(tmax.item()), float(ssum.item())
+    else:
+        sweeps_all = float(sweeps_local)
+
+    # one extra, instrumented solve: HIP events around every sweep launch on the
+    # library's own stream (not part of the timed region)
+    sol.set_option(P.OPT_TIMING, 1)
+    sol.solve_device(my_starts, tt, init=True)
+    st = sol.stats()
+    sol.set_option(P.OPT_TIMING, 0)
+
+    if rank == 0:
+        kern_s = st["sweep_kernel_ms"] / 1e3
+        launches = max(st["launches"], 1)
+        alg_bytes = BYTES_PER_CELL_SWEEP * cells * st["sweeps_total"]
+        relax = st["relaxations_per_sweep"] * st["sweeps_total"]
+        achieved = alg_bytes / kern_s / 1e9 if kern_s > 0 else 0.0
+        lane = LANEOPS_PER_RELAX * relax / kern_s / 1e12 if kern_s > 0 else 0.0
+        out = {
+            "metric": "Mcells*sweeps/s (241x241x51, 818-offset star, 24 starts, to convergence)",
+            "value": cells * sweeps_all / dt / 1e6,
+            "unit": "Mcells*sweeps/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{nx}x{ny}x{nz} synthetic velocity, {args.star}-FS star, "
+                                   f"{nstart} starts (start-{args.starts}), converged multi-start solve",
+                       "grid": [nx, ny, nz], "star_offsets": int(len(offs)), "starts": int(nstart),
+                       "starts_per_gpu": len(mine), "parallelism": f"starts sharded over {world} GPU(s)",
+                       "kernel_variant": st["kernel_variant"],
+                       "sweeps_per_start_mean": sweeps_all / args.steps / nstart},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "kernel": "sweep", "launches": int(launches),
+                         "avg_launch_ms": st["sweep_kernel_ms"] / launches,
+                         "algorithmic_bytes_per_launch": alg_bytes / launches,
+                         "note": "12 B per cell*pass; with 817 relaxations per cell*pass this star is "
+                                 "VALU-bound, see roofline_valu"},
+            "roofline_valu": {"achieved": lane, "peak": VALU_PEAK_TLANEOPS, "unit": "Tlane-ops/s",
+                              "frac": lane / VALU_PEAK_TLANEOPS,
+                              "relaxations_per_pass": st["relaxations_per_sweep"],
+                              "laneops_per_relaxation": LANEOPS_PER_RELAX},
+        }
+        if world == 1 and not args.no_cpu and v_host is not None:
+            out["cpu_baseline"] = cpu_baseline(P, v_host, offs, starts[0])
+        print(json.dumps(out), flush=True)
+    sol.close()
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,155 @@
+/* ttsweep.h - C ABI of the MI355X travel-time sweep library (libttsweep.so).
+ *
+ * This is the drop-in boundary for the hot path of the reference program
+ * serial_new/sweep-tt-multistart.c: the file-local call
+ *     changed[s] += sweepXYZ(nx, ny, nz, s, 0, starsize-1);        (:160)
+ * inside the `while (anychange)` driver loop (:151-170), which reads the
+ * file-scope globals fs[], start[], vbox and ttboxes[] (:62-66).  Nothing but
+ * plain pointers, ints and the two small POD structs below crosses this
+ * boundary; no FLOATBOX/VELOCITYBOX struct and no torch type does.
+ *
+ * Data layout at the boundary is the reference's FLOATBOX layout
+ * (include/floatbox.h:127-129,160): a contiguous float32 array indexed
+ * x*ny*nz + y*nz + z.  The library keeps its own padded/permuted device
+ * copies; caller buffers are never re-allocated or freed by the library.
+ *
+ * Semantics.  One library "solve" is the reference's driver loop run to its
+ * end: it relaxes every live edge of the forward star until no travel time
+ * can improve (the `while (anychange)` loop without the temporary `break` of
+ * :168-169; see old/sweep-serial/sweep-tt-multistart.c:189-211).  The
+ * converged box does not depend on the order of relaxation, so the GPU is free
+ * to use its own schedule and reproduces the serial fixed point bit for bit,
+ * including the reference's two quirks (exclusive upper star bound at :160/:206
+ * and the skipped edges centred on the start point, :219-221).
+ *
+ * Error convention: functions returning int return a negative value on a
+ * HIP/argument error (text via ttsweep_last_error()); the reference's own
+ * "0 = failure" convention stays on the header surface (floatbox.h etc.).
+ * There is NO CPU fallback: without a usable HIP device every solve fails.
+ */
+#ifndef TTSWEEP_H
+#define TTSWEEP_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TTSWEEP_ABI_VERSION 1
+
+/* Forward-star entry: same layout as `struct FS`
+ * (serial_new/sweep-tt-multistart.c:46-49).  d must already hold
+ * delta * |offset| exactly as the reference main() prepares it (:122,:127). */
+typedef struct ttsweep_fs {
+    int i, j, k;
+    float d;
+} ttsweep_fs;
+
+/* Start point: same layout as `struct START` (serial_new/...:56-58). */
+typedef struct ttsweep_start {
+    int i, j, k;
+} ttsweep_start;
+
+/* Counters of the most recent solve on a context. */
+typedef struct ttsweep_stats {
+    int nstart;                 /* starts in the solve */
+    int sweeps_max;             /* full-grid passes executed for the slowest start */
+    long long sweeps_total;     /* sum over starts of full-grid passes executed */
+    long long cells;            /* nx*ny*nz */
+    long long relaxations_per_sweep; /* in-bounds (cell, offset) pairs one pass relaxes */
+    long long launches;         /* sweep-kernel launches */
+    double sweep_kernel_ms;     /* sum of sweep-kernel durations (HIP events on the
+                                   library's stream; 0 unless timing is enabled) */
+    double solve_ms;            /* device time of the whole solve (events) */
+    int kernel_variant;         /* which sweep kernel ran (TTSWEEP_KERNEL_*) */
+} ttsweep_stats;
+
+typedef struct ttsweep_ctx ttsweep_ctx;
+
+/* option keys for ttsweep_set_option */
+#define TTSWEEP_OPT_TIMING        1   /* 1: time every sweep launch with HIP events */
+#define TTSWEEP_OPT_KERNEL        2   /* force a kernel variant (TTSWEEP_KERNEL_*) */
+#define TTSWEEP_OPT_MAX_SWEEPS    3   /* safety cap on passes per solve (default 100000) */
+#define TTSWEEP_OPT_BATCH_SWEEPS  4   /* passes enqueued between convergence checks */
+
+#define TTSWEEP_KERNEL_AUTO       0
+#define TTSWEEP_KERNEL_CELL       1   /* one thread per cell, star from global memory */
+#define TTSWEEP_KERNEL_STRIP      2   /* LDS-staged plane slabs, register strips */
+
+/* ---- information ------------------------------------------------------- */
+int ttsweep_abi_version(void);
+/* number of HIP devices, or a negative value when HIP cannot be initialised */
+int ttsweep_device_count(void);
+/* text of the most recent error on this thread ("" if none) */
+const char *ttsweep_last_error(void);
+
+/* ---- context ----------------------------------------------------------- */
+/* Create a solver for an nx*ny*nz grid and the star entries
+ * fs[starstart .. starstop-1] (EXCLUSIVE upper bound, as the reference call
+ * site passes starsize-1, :160).  Uploads the star to `device`.
+ * Replaces: the globals fs[] / nx,ny,nz and the (starstart, starstop)
+ * arguments of sweepXYZ (:198).  Returns NULL on failure. */
+ttsweep_ctx *ttsweep_create(int device, int nx, int ny, int nz,
+                            const ttsweep_fs *fs, int starstart, int starstop);
+void ttsweep_destroy(ttsweep_ctx *ctx);
+
+int ttsweep_set_option(ttsweep_ctx *ctx, int key, long long value);
+
+/* Velocity volume (the global `vbox.box.flat`, :65), host or device memory,
+ * FLOATBOX layout.  The library keeps its own device copy. */
+int ttsweep_set_velocity(ttsweep_ctx *ctx, const float *v_host);
+int ttsweep_set_velocity_device(ttsweep_ctx *ctx, const float *v_dev);
+
+/* ---- the hot path ------------------------------------------------------ */
+/* Relax nstart travel-time boxes to convergence.
+ *   starts[s]  : the start point of box s (global start[], :63)
+ *   tt[s]      : box s (global ttboxes[s].flat, :66), FLOATBOX layout; read as
+ *                the initial state and overwritten with the converged state.
+ * Returns 1 if any travel time improved, 0 if every box was already converged
+ * (the two outcomes `anychange != 0` / `== 0` of :163-166), < 0 on error.
+ * Replaces: the whole `while (anychange)` loop of :151-170 over all starts. */
+int ttsweep_solve(ttsweep_ctx *ctx, int nstart, const ttsweep_start *starts,
+                  float *const *tt_host);
+
+/* Same, with the boxes in device memory (pointers are device addresses held
+ * in a host array).  If init != 0 the incoming contents are ignored and every
+ * box starts from the reference initial state (all +INFINITY, start = 0;
+ * serial_new/...:139-144), which is then done on the device. */
+int ttsweep_solve_device(ttsweep_ctx *ctx, int nstart, const ttsweep_start *starts,
+                         float *const *tt_dev, int init);
+
+int ttsweep_get_stats(const ttsweep_ctx *ctx, ttsweep_stats *out);
+
+/* One-call drop-in for the reference's
+ *   int sweepXYZ(int nx,int ny,int nz,int s,int starstart,int starstop)  (:198)
+ * with the globals it reads passed explicitly: v = vbox.box.flat,
+ * tt = ttboxes[s].flat, fs = fs, (si,sj,sk) = start[s].  Runs to convergence
+ * on device 0 and returns > 0 if anything improved, 0 if not (so the
+ * reference driver loop terminates after the next call), < 0 on error.
+ * Creates and destroys a context per call; use the context API for batches. */
+int ttsweep_sweepXYZ(const float *v, float *tt, int nx, int ny, int nz,
+                     const ttsweep_fs *fs, int starstart, int starstop,
+                     int si, int sj, int sk);
+
+/* ---- host-only helpers (no device needed; used by the CPU test tier) ---- */
+/* Build the pull form of the star: fills up to cap entries of
+ * (di,dj,dk,flags,h) and returns the entry count (also when cap is too
+ * small), < 0 on error.  flags bit0: live unless the centre cell is the
+ * start; bit1: live unless the neighbour is the start. */
+typedef struct ttsweep_pull_entry {
+    int di, dj, dk;
+    int flags;
+    float h;        /* d/2, so delay = h * (v[c] + v[o]) */
+} ttsweep_pull_entry;
+int ttsweep_build_pull_star(const ttsweep_fs *fs, int starstart, int starstop,
+                            ttsweep_pull_entry *out, int cap);
+
+/* In-bounds (cell, offset) pairs of one reference pass: the closed form
+ * sum over l in [starstart,starstop) of prod_axis max(n_axis - |off|, 0). */
+long long ttsweep_relaxations_per_sweep(int nx, int ny, int nz, const ttsweep_fs *fs,
+                                        int starstart, int starstop);
+
+#ifdef __cplusplus
+}
+#endif
+
+#endif /* TTSWEEP_H */

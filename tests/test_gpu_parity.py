@@ -1,0 +1,183 @@
+"""GPU tier (-m gpu): the HIP path, called through the C ABI, against
+  * the committed golden fixtures recorded from the reference itself,
+  * the CPU oracle on the same seeded inputs,
+  * size-independent properties at BASELINE.json's full grid size.
+Bar: bit-exact (BASELINE.json asks <= 1e-5 relative; the converged state is
+order-independent, so equality is achievable and is what is asserted)."""
+import hashlib
+import json
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, assert_bit_equal
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def P(pkg):
+    n = pkg.device_count()
+    assert n > 0, "no HIP device: the GPU tier must run on an MI355X (there is no CPU fallback)"
+    return pkg
+
+
+def gpu_converge(P, v, fs, starts, starstart=0, starstop=None, tts=None, kernel=None):
+    starts = np.asarray(starts, dtype=np.int32).reshape(-1, 3)
+    with P.TravelTimeSolver(v.shape, fs, starstart, starstop) as sol:
+        if kernel is not None:
+            sol.set_option(P.OPT_KERNEL, kernel)
+        sol.set_velocity(v)
+        if tts is None:
+            tts = []
+            for st in starts:
+                tt = np.full(v.shape, np.inf, dtype=np.float32)
+                tt[tuple(st)] = 0
+                tts.append(tt)
+        rc = sol.solve(starts, tts)
+        return tts, rc, sol.stats()
+
+
+def test_golden_cases_bit_exact(P, golden):
+    """Every fixture: 5 stars (3 shipped, one non-symmetric, 6-neighbour) x 4 start
+    kinds (interior, corner, dead edge inside / outside the grid)."""
+    n = 0
+    for key, sname, offs, start, want, _ in golden.cases():
+        fs = P.inputs.make_fs(offs)
+        (tt,), rc, st = gpu_converge(P, golden.v, fs, [start])
+        assert rc == 1, key
+        assert_bit_equal(tt, want, key)
+        assert st["sweeps_total"] >= 2
+        n += 1
+    assert n == 20
+
+
+def test_golden_star_subrange(P, golden):
+    m = golden.meta["3_range_5_60"]
+    fs = P.inputs.make_fs(golden.star("3"))
+    (tt,), _, _ = gpu_converge(P, golden.v, fs, [m["start"]], starstart=5, starstop=60)
+    assert_bit_equal(tt, golden.z["tt_3_range_5_60"], "range")
+
+
+def test_batch_of_starts_equals_single_solves(P, golden24):
+    """All four start kinds of one star in one batched solve."""
+    offs = golden24.star("818")
+    fs = P.inputs.make_fs(offs)
+    keys = ["818_mid", "818_corner", "818_deadin", "818_deadout"]
+    starts = [golden24.z[f"start_{k}"] for k in keys]
+    tts, rc, st = gpu_converge(P, golden24.v, fs, starts)
+    assert rc == 1 and st["nstart"] == 4
+    for k, tt in zip(keys, tts):
+        assert_bit_equal(tt, golden24.z[f"tt_{k}"], k)
+
+
+def test_resume_and_idempotence(P, golden24, oracle):
+    """The solve takes the box as its initial state: starting from the reference's
+    state after ONE pass reaches the same fixed point, and solving a converged box
+    returns 0 and leaves it untouched (the loop exit of serial_new/...:152,166)."""
+    m = golden24.meta["pass_818"]
+    fs = P.inputs.make_fs(golden24.star("818"))
+    tt = golden24.z["pass1_818"].copy()
+    (tt,), rc, _ = gpu_converge(P, golden24.v, fs, [m["start"]], tts=[tt])
+    assert rc == 1
+    want, _, _ = oracle.converge(golden24.v, oracle.make_star(golden24.star("818")), m["start"])
+    assert_bit_equal(tt, want, "resume")
+    before = tt.copy()
+    (tt,), rc, st = gpu_converge(P, golden24.v, fs, [m["start"]], tts=[tt])
+    assert rc == 0 and st["sweeps_total"] == 1
+    assert_bit_equal(tt, before, "idempotent")
+
+
+def test_sweepXYZ_dropin(P, golden24):
+    """ttsweep_sweepXYZ: non-zero on the first call, 0 on the next (drop-in contract)."""
+    key = "3_mid"
+    fs = P.inputs.make_fs(golden24.star("3"))
+    start = golden24.z[f"start_{key}"]
+    tt = np.full(golden24.v.shape, np.inf, dtype=np.float32)
+    tt[tuple(start)] = 0
+    assert P.sweepXYZ(golden24.v, tt, fs, start) > 0
+    assert_bit_equal(tt, golden24.z[f"tt_{key}"], key)
+    assert P.sweepXYZ(golden24.v, tt, fs, start) == 0
+
+
+@pytest.mark.parametrize("shape,seed", [((33, 70, 19), 11), ((70, 33, 40), 12), ((5, 4, 3), 13),
+                                        ((1, 1, 1), 14), ((2, 300, 2), 15), ((130, 3, 66), 16)])
+def test_seeded_random_vs_oracle(P, oracle, shape, seed):
+    """Ragged / tiny / thin grids (smaller than the star radius on some axes) with
+    random velocities and a random asymmetric star, against the CPU oracle."""
+    rng = np.random.default_rng(seed)
+    v = rng.uniform(0.1, 0.5, size=shape).astype(np.float32)
+    offs = rng.integers(-7, 8, size=(60, 3)).astype(np.int32)
+    offs = offs[np.any(offs != 0, axis=1)]
+    start = [int(rng.integers(0, n)) for n in shape]
+    want, _, _ = oracle.converge(v, oracle.make_star(offs), start, order=1)
+    (tt,), _, _ = gpu_converge(P, v, P.inputs.make_fs(offs), [start])
+    assert_bit_equal(tt, want, str(shape))
+
+
+def test_device_resident_solve(P, golden24):
+    """ttsweep_solve_device with init on the device (the bench path)."""
+    import torch
+    offs = golden24.star("5")
+    fs = P.inputs.make_fs(offs)
+    keys = ["5_mid", "5_corner"]
+    starts = np.array([golden24.z[f"start_{k}"] for k in keys], dtype=np.int32)
+    dev = torch.device("cuda:0")
+    with P.TravelTimeSolver(golden24.v.shape, fs) as sol:
+        sol.set_velocity(torch.from_numpy(golden24.v).to(dev))
+        tt = torch.empty((2,) + golden24.v.shape, dtype=torch.float32, device=dev)
+        assert sol.solve_device(starts, tt, init=True) == 1
+        out = tt.cpu().numpy()
+    for n, k in enumerate(keys):
+        assert_bit_equal(out[n], golden24.z[f"tt_{k}"], k)
+
+
+# ---------------------------------------------------------------------------
+# BASELINE.json full size: 241 x 241 x 51
+# ---------------------------------------------------------------------------
+
+@pytest.fixture(scope="module")
+def full(P):
+    return P.inputs.velocity_model(241, 241, 51, 20160507)
+
+
+def test_full_size_digests(P, full):
+    """Converged 241x241x51 boxes equal the reference's (SHA-256 recorded from the
+    reference run; start (120,120,50); includes the dead-edge cell (113,119,49))."""
+    path = os.path.join(GOLDEN, "big_digests.json")
+    digests = json.load(open(path))
+    ran = 0
+    for sname in ("3", "818"):
+        want = digests.get(f"syn241_{sname}_120_120_50")
+        if want is None:
+            continue
+        fs = P.inputs.make_fs(P.inputs.read_triples(P.inputs.star_path(sname)))
+        (tt,), rc, st = gpu_converge(P, full, fs, [(120, 120, 50)])
+        for pos, b in want["spots"].items():
+            p = tuple(map(int, pos.split(",")))
+            assert int(tt[p].view(np.uint32)) == b, (sname, p)
+        assert hashlib.sha256(tt.tobytes()).hexdigest() == want["sha256"], sname
+        ran += 1
+    assert ran >= 1
+
+
+def test_full_size_fixed_point_properties(P, oracle, full):
+    """start-4 (the BASELINE config), 818-FS: no INFINITY left, start at 0, a second
+    solve changes nothing, and the oracle's validator finds no relaxable edge
+    (one CPU pass, ~15 s) for one of the starts."""
+    fs = P.inputs.make_fs(P.inputs.read_triples(P.inputs.star_path("818")))
+    starts = P.inputs.read_triples(P.inputs.starts_path("4"))
+    tts, rc, st = gpu_converge(P, full, fs, starts)
+    assert rc == 1
+    for s, tt in zip(starts, tts):
+        assert np.isfinite(tt).all()
+        assert tt[tuple(s)] == 0 and (tt >= 0).all()
+    again = [t.copy() for t in tts]
+    _, rc2, st2 = gpu_converge(P, full, fs, starts, tts=again)
+    assert rc2 == 0 and st2["sweeps_total"] == len(starts)
+    for a, b in zip(again, tts):
+        assert_bit_equal(a, b, "idempotent")
+    open_edges, ninf = oracle.validate(full, tts[0], oracle.make_star(
+        oracle.read_triples(P.inputs.star_path("818"))), starts[0])
+    assert (open_edges, ninf) == (0, 0)

@@ -1,0 +1,15 @@
+"""MI355X-native multi-start travel-time sweep (host-side Python mirror of include/ttsweep.h).
+
+The directory name contains a hyphen, so import it through `ttsweep_pkg.load()` at
+the repository root (it registers this package as `uoparallel_seismic_project_amd`).
+"""
+from . import _lib, inputs, multistart, solver
+from ._lib import (KERNEL_AUTO, KERNEL_CELL, KERNEL_STRIP, OPT_BATCH_SWEEPS, OPT_KERNEL,
+                   OPT_MAX_SWEEPS, OPT_TIMING)
+from .solver import (TravelTimeSolver, TTSweepError, build_pull_star, device_count,
+                     relaxations_per_sweep, sweepXYZ)
+
+__all__ = ["_lib", "inputs", "multistart", "solver", "TravelTimeSolver", "TTSweepError",
+           "build_pull_star", "device_count", "relaxations_per_sweep", "sweepXYZ",
+           "KERNEL_AUTO", "KERNEL_CELL", "KERNEL_STRIP", "OPT_TIMING", "OPT_KERNEL",
+           "OPT_MAX_SWEEPS", "OPT_BATCH_SWEEPS"]

@@ -1,0 +1,28 @@
+// ttsweep_kernels.h - launchers of the HIP kernels (ttsweep_kernels.hip).
+#pragma once
+
+#include "ttsweep_dev.h"
+
+namespace ttsweep {
+
+// ---- layout conversion / initialisation -----------------------------------
+// user FLOATBOX array -> padded device volume; halo cells get `halo_value`.
+hipError_t launch_pack(const DevLayout &L, const float *user, float *padded,
+                       float halo_value, hipStream_t st);
+// padded device volume -> user FLOATBOX array (interior only).
+hipError_t launch_unpack(const DevLayout &L, const float *padded, float *user,
+                         hipStream_t st);
+// reference initial state: everything +INFINITY, the start cell 0
+// (serial_new/sweep-tt-multistart.c:139-144).
+hipError_t launch_init_tt(const DevLayout &L, float *padded, long long sidx,
+                          hipStream_t st);
+
+// ---- sweep, variant CELL ---------------------------------------------------
+// One chaotic in-place pull pass over the whole grid for the `nactive` starts
+// listed in `active`; changed[s] is OR-ed with 1 when any cell of start s
+// improved.
+hipError_t launch_sweep_cell(const DevLayout &L, const float *v, const StartDesc *starts,
+                             const int *active, int nactive, int *changed,
+                             const CellEntry *entries, int nentries, hipStream_t st);
+
+} // namespace ttsweep

@@ -1,0 +1,242 @@
+/* sweep-tt-multistart.c - plain-C host program of the MI355X travel-time solver.
+ *
+ * Same command line, same progress output and same "output.tt" as the
+ * reference program serial_new/sweep-tt-multistart.c:
+ *
+ *      sweep-tt-multistart vfile fsfile startfile
+ *
+ *   vfile      velocity volume in .vbox format (formats/VBOXFORMAT.txt)
+ *   fsfile     forward star:  "starsize" then "oi oj ok" per offset
+ *   startfile  start points:  "numstart" then "si sj sk" per start
+ *
+ * main() follows the reference's main() (:70-195) step by step and keeps its
+ * file-scope globals (fs, start, vbox, ttboxes, changed: :60-66) and its call
+ *      changed[s] += sweepXYZ(nx, ny, nz, s, 0, starsize-1);            (:160)
+ * What changed is the callee: sweepXYZ() no longer relaxes on the CPU, it
+ * forwards raw pointers to libttsweep.so (include/ttsweep.h), which relaxes
+ * on the GPU until nothing improves.  The driver loop therefore runs twice:
+ * the first pass converges every start (changed != 0), the second confirms
+ * (changed == 0).  The reference's temporary `break` after one sweep
+ * (:168-169) is not reproduced: a one-sweep state depends on the relaxation
+ * order, the converged state does not.
+ *
+ * Differences from the reference that do not affect results: STARTMAX is 128
+ * instead of 12 (start-24 / start-111 overflow the reference's arrays), the
+ * argument count is checked, and the "cannot open starting points" message
+ * prints argv[3] (the reference prints argv[4], :102).
+ *
+ * Environment: TTSWEEP_DEVICE=<n> selects the GPU (default 0);
+ * TTSWEEP_NO_OUTPUT=1 skips writing output.tt (2.96 M text lines per start).
+ */
+#include "velocityboxfiler.h"
+#include "ttsweep.h"
+
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+
+#define FSRADIUSMAX 7       /* maximum radius forward star */
+#define FSMAX       818     /* maximum # of points in a forward star */
+#define STARTMAX    128     /* maximum starting points */
+
+struct FS {                 /* forward star offset (== ttsweep_fs) */
+    int   i, j, k;
+    float d;                /* delta * distance to the star centre */
+};
+
+struct START {              /* starting point (== ttsweep_start) */
+    int i, j, k;
+};
+
+int changed[STARTMAX];
+
+struct FS    fs[FSMAX];
+struct START start[STARTMAX];
+
+struct VELOCITYBOX vbox;                /* velocities */
+struct FLOATBOX    ttboxes[STARTMAX];   /* one travel-time volume per start */
+
+int sweepXYZ(int nx, int ny, int nz, int s, int starstart, int starstop);
+
+static int numstart_g = 0;              /* sweepXYZ batches all starts of a pass */
+
+int main(int argc, char *argv[])
+{
+    int   i, j, k, nx, ny, nz, s;
+    int   numradius, starsize, anychange, numstart, numsweeps = 0;
+    int   fsindex[FSRADIUSMAX];
+    float delta;
+    FILE *fsfile, *ttfile, *startfile;
+    const char *velocity_model_file;
+
+    if (argc < 4) {
+        printf("usage: %s vfile fsfile startfile\n", argv[0]);
+        exit(1);
+    }
+    velocity_model_file = argv[1];
+
+    /* open velocity model file */
+    printf("Loading velocity model file: %s...", velocity_model_file); fflush(stdout);
+    if (!vbfileloadbinary(&vbox, velocity_model_file)) {
+        printf("Cannot open velocity model file: %s\n", velocity_model_file);
+        exit(1);
+    }
+    nx = vbox.box.size.x;
+    ny = vbox.box.size.y;
+    nz = vbox.box.size.z;
+    printf(" done.\n"); fflush(stdout);
+    printf("Velocity model dimensions: %d x %d x %d\n", nx, ny, nz);
+
+    /* open forward star offset file */
+    fsfile = fopen(argv[2], "r");
+    if (fsfile == NULL) {
+        printf("Cannot open forward star offset file: %s\n", argv[2]);
+        exit(1);
+    }
+    printf("Forward star offset file: %s\n", argv[2]);
+
+    /* open file with starting points */
+    startfile = fopen(argv[3], "r");
+    if (startfile == NULL) {
+        printf("Cannot open starting points file: %s\n", argv[3]);
+        exit(1);
+    }
+    printf("Starting points file: %s\n", argv[3]);
+
+    /* get delta */
+    delta = 10.0;
+    printf("Delta: %f\n", delta);
+
+    /* read forward star offsets */
+    starsize = 0;
+    if (fscanf(fsfile, "%i", &starsize) != 1 || starsize < 1 || starsize > FSMAX) {
+        printf("Bad forward star size in %s (maximum %d)\n", argv[2], FSMAX);
+        exit(1);
+    }
+    printf("Forward star size: %d\n", starsize);
+
+    for (i = 0; i < FSRADIUSMAX; i++) fsindex[i] = 0;
+    numradius = 0;
+    for (i = 0; i < starsize; i++) {
+        if (fscanf(fsfile, "%i %i %i", &fs[i].i, &fs[i].j, &fs[i].k) != 3) {
+            printf("Bad forward star entry %d in %s\n", i, argv[2]);
+            exit(1);
+        }
+        fs[i].d = sqrt(fs[i].i * fs[i].i + fs[i].j * fs[i].j + fs[i].k * fs[i].k);
+        if ((numradius + 1) < fs[i].d && numradius < FSRADIUSMAX) {
+            fsindex[numradius] = i;
+            numradius++;
+        }
+        fs[i].d = delta * fs[i].d;
+    }
+    fclose(fsfile);
+    printf("Forward star offsets read\n");
+    for (i = 0; i < FSRADIUSMAX; i++)
+        printf("numradius: %d, fsindex[%d]: %d\n", numradius, i, fsindex[i]);
+
+    /* read starting points */
+    if (fscanf(startfile, "%i", &numstart) != 1 || numstart < 0 || numstart > STARTMAX) {
+        printf("Bad number of starting points in %s (maximum %d)\n", argv[3], STARTMAX);
+        exit(1);
+    }
+    for (s = 0; s < numstart; s++) {
+        /* prepare travel time volumes */
+        if (!boxalloc(&ttboxes[s], nx, ny, nz)) {
+            printf("Cannot allocate travel time volume %d\n", s);
+            exit(1);
+        }
+        boxsetall(ttboxes[s], INFINITY);
+
+        /* set the starting point to have a travel time of 0 */
+        if (fscanf(startfile, "%i %i %i", &i, &j, &k) != 3
+            || i < 0 || i >= nx || j < 0 || j >= ny || k < 0 || k >= nz) {
+            printf("Bad starting point %d in %s\n", s, argv[3]);
+            exit(1);
+        }
+        boxput(ttboxes[s], i, j, k, 0);
+        printf("starting point %d: %d %d %d\n", s, i, j, k);
+        start[s].i = i; start[s].j = j; start[s].k = k;
+    }
+    fclose(startfile);
+    printf("Starting points read\n");
+    numstart_g = numstart;
+
+    /* sweep until no change in travel times occur */
+    anychange = 1;
+    while (anychange) {
+        numsweeps++;
+        anychange = 0;
+        printf("sweep %d begin\n", numsweeps);
+
+        for (s = 0; s < numstart; s++) {
+            changed[s] = 0;
+            changed[s] += sweepXYZ(nx, ny, nz, s, 0, starsize - 1);
+            printf(">>> start %d: changed == %d\n", s, changed[s]);
+        }
+        for (s = 0; s < numstart; s++) anychange += changed[s];
+        printf("sweep %d finished: anychange = %d\n", numsweeps, anychange);
+    }
+
+    /* print travel times */
+    if (getenv("TTSWEEP_NO_OUTPUT") == NULL) {
+        ttfile = fopen("output.tt", "w");
+        if (ttfile == NULL) {
+            printf("Can not open travel time output file: %s\n", "output.tt");
+            exit(1);
+        }
+        fprintf(ttfile, "%d %d %d\n", nx, ny, nz);
+        for (s = 0; s < numstart; s++) {
+            fprintf(ttfile, "starting point: %d\n", s);
+            for (i = 0; i < nx; i++)
+                for (j = 0; j < ny; j++)
+                    for (k = 0; k < nz; k++)
+                        fprintf(ttfile, "travel time for (%d,%d,%d): %f %d %d %d\n",
+                                i, j, k, boxget(ttboxes[s], i, j, k), 0, 0, 0);
+        }
+        fclose(ttfile);
+    }
+    return 0;
+} /* main */
+
+
+/* Drop-in for the reference's sweepXYZ (:198-256).  The first call of a pass
+ * (s == 0) hands ALL starts to the library in one batched solve (they share
+ * the velocity volume on the device); the calls for s > 0 only report what
+ * that solve found for their start. */
+int sweepXYZ(int nx, int ny, int nz, int s, int starstart, int starstop)
+{
+    static ttsweep_ctx *ctx = NULL;
+    static int result[STARTMAX];
+    int n;
+
+    if (ctx == NULL) {
+        const char *dev = getenv("TTSWEEP_DEVICE");
+        ctx = ttsweep_create(dev ? atoi(dev) : 0, nx, ny, nz,
+                             (const ttsweep_fs *)fs, starstart, starstop);
+        if (ctx == NULL || ttsweep_set_velocity(ctx, vbox.box.flat) < 0) {
+            printf("ttsweep: %s\n", ttsweep_last_error());
+            exit(1);
+        }
+    }
+    if (s == 0) {
+        float *boxes[STARTMAX];
+        for (n = 0; n < numstart_g; n++) boxes[n] = ttboxes[n].flat;
+        /* per-start outcome: solve the batch, then ask which boxes moved */
+        for (n = 0; n < numstart_g; n++) result[n] = 0;
+        {
+            ttsweep_stats st;
+            int rc = ttsweep_solve(ctx, numstart_g, (const ttsweep_start *)start, boxes);
+            if (rc < 0) {
+                printf("ttsweep: %s\n", ttsweep_last_error());
+                exit(1);
+            }
+            ttsweep_get_stats(ctx, &st);
+            /* a start that needed more than its single confirming pass improved */
+            for (n = 0; n < numstart_g; n++) result[n] = rc;
+            if (rc > 0)
+                printf("ttsweep: %d starts, %lld sweeps in total (max %d), %.3f ms on device\n",
+                       st.nstart, st.sweeps_total, st.sweeps_max, st.solve_ms);
+        }
+    }
+    return result[s];
+} /* end sweepXYZ */

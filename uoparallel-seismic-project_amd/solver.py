@@ -1,0 +1,162 @@
+"""Python mirror of the C ABI in include/ttsweep.h (thin ctypes layer, no compute).
+
+`TravelTimeSolver` wraps one `ttsweep_ctx`.  Method names follow the C entry
+points; array arguments use the reference's FLOATBOX layout ([x][y][z], z fastest,
+include/floatbox.h:127-129).  All arithmetic happens in libttsweep.so on the GPU;
+if the library or a HIP device is missing every call raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import FS, PullEntry, Start, Stats
+from .inputs import FS_DTYPE
+
+
+class TTSweepError(RuntimeError):
+    pass
+
+
+def _check(rc: int, what: str) -> int:
+    if rc < 0:
+        raise TTSweepError(f"{what}: {_lib.last_error()}")
+    return rc
+
+
+def device_count() -> int:
+    return _check(_lib.lib().ttsweep_device_count(), "ttsweep_device_count")
+
+
+def build_pull_star(fs: np.ndarray, starstart: int = 0, starstop: int | None = None):
+    """Host-only: the pull form of the star as a list of (di,dj,dk,flags,h)."""
+    fs = np.ascontiguousarray(fs, dtype=FS_DTYPE)
+    if starstop is None:
+        starstop = len(fs) - 1
+    cap = 2 * max(len(fs), 1)
+    buf = (PullEntry * cap)()
+    n = _check(_lib.lib().ttsweep_build_pull_star(fs.ctypes.data, starstart, starstop, buf, cap),
+               "ttsweep_build_pull_star")
+    return [(e.di, e.dj, e.dk, e.flags, e.h) for e in buf[:n]]
+
+
+def relaxations_per_sweep(shape, fs: np.ndarray, starstart: int = 0, starstop: int | None = None) -> int:
+    fs = np.ascontiguousarray(fs, dtype=FS_DTYPE)
+    if starstop is None:
+        starstop = len(fs) - 1
+    return _lib.lib().ttsweep_relaxations_per_sweep(*map(int, shape), fs.ctypes.data,
+                                                    starstart, starstop)
+
+
+class TravelTimeSolver:
+    """One solver context: a grid size, a star range and a device.
+
+    starstop defaults to len(fs)-1, the (exclusive) bound the reference call site
+    passes (serial_new/sweep-tt-multistart.c:160)."""
+
+    def __init__(self, shape, fs: np.ndarray, starstart: int = 0, starstop: int | None = None,
+                 device: int = 0):
+        self._L = _lib.lib()
+        self.shape = tuple(int(n) for n in shape)
+        self.fs = np.ascontiguousarray(fs, dtype=FS_DTYPE)
+        self.starstart = starstart
+        self.starstop = len(self.fs) - 1 if starstop is None else starstop
+        self.device = device
+        self._ctx = self._L.ttsweep_create(device, *self.shape, self.fs.ctypes.data,
+                                           self.starstart, self.starstop)
+        if not self._ctx:
+            raise TTSweepError(f"ttsweep_create: {_lib.last_error()}")
+
+    # -- lifecycle ----------------------------------------------------------
+    def close(self):
+        if getattr(self, "_ctx", None):
+            self._L.ttsweep_destroy(self._ctx)
+            self._ctx = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def set_option(self, key: int, value: int):
+        _check(self._L.ttsweep_set_option(self._ctx, key, value), "ttsweep_set_option")
+
+    # -- inputs -------------------------------------------------------------
+    def set_velocity(self, v):
+        """v: numpy float32 [nx,ny,nz] (host) or a CUDA/HIP torch tensor (device)."""
+        if isinstance(v, np.ndarray):
+            v = np.ascontiguousarray(v, dtype=np.float32)
+            assert v.shape == self.shape
+            _check(self._L.ttsweep_set_velocity(self._ctx, v.ctypes.data), "ttsweep_set_velocity")
+        else:
+            import torch
+            assert v.is_cuda and v.dtype == torch.float32 and v.is_contiguous()
+            assert tuple(v.shape) == self.shape
+            torch.cuda.current_stream(v.device).synchronize()
+            _check(self._L.ttsweep_set_velocity_device(self._ctx, v.data_ptr()),
+                   "ttsweep_set_velocity_device")
+
+    # -- the hot path -------------------------------------------------------
+    @staticmethod
+    def _starts_array(starts):
+        starts = np.asarray(starts, dtype=np.int32).reshape(-1, 3)
+        arr = (Start * len(starts))()
+        for s, (i, j, k) in enumerate(starts):
+            arr[s] = Start(int(i), int(j), int(k))
+        return arr
+
+    def solve(self, starts, tt_boxes) -> int:
+        """In-place solve of host boxes (numpy float32 arrays, one per start).
+        Returns 1 if anything improved, 0 if all boxes were already converged."""
+        arr = self._starts_array(starts)
+        assert len(tt_boxes) == len(arr)
+        ptrs = (C.c_void_p * len(arr))()
+        for s, box in enumerate(tt_boxes):
+            assert isinstance(box, np.ndarray) and box.dtype == np.float32
+            assert box.flags["C_CONTIGUOUS"] and box.shape == self.shape
+            ptrs[s] = box.ctypes.data
+        return _check(self._L.ttsweep_solve(self._ctx, len(arr), arr, ptrs), "ttsweep_solve")
+
+    def solve_device(self, starts, tt, init: bool = True) -> int:
+        """Solve with the boxes resident in HBM.  tt: torch float32 tensor
+        [nstart,nx,ny,nz] on this solver's device, written in place."""
+        import torch
+        arr = self._starts_array(starts)
+        assert tt.is_cuda and tt.dtype == torch.float32 and tt.is_contiguous()
+        assert tuple(tt.shape) == (len(arr),) + self.shape
+        ptrs = (C.c_void_p * len(arr))()
+        stride = tt.stride(0) * 4
+        for s in range(len(arr)):
+            ptrs[s] = tt.data_ptr() + s * stride
+        torch.cuda.current_stream(tt.device).synchronize()
+        return _check(self._L.ttsweep_solve_device(self._ctx, len(arr), arr, ptrs, int(init)),
+                      "ttsweep_solve_device")
+
+    def stats(self) -> dict:
+        st = Stats()
+        _check(self._L.ttsweep_get_stats(self._ctx, C.byref(st)), "ttsweep_get_stats")
+        return {name: getattr(st, name) for name, _ in Stats._fields_}
+
+
+def sweepXYZ(v: np.ndarray, tt: np.ndarray, fs: np.ndarray, start, starstart: int = 0,
+             starstop: int | None = None) -> int:
+    """The one-call drop-in (ttsweep_sweepXYZ): converge `tt` in place on device 0."""
+    v = np.ascontiguousarray(v, dtype=np.float32)
+    fs = np.ascontiguousarray(fs, dtype=FS_DTYPE)
+    assert tt.dtype == np.float32 and tt.flags["C_CONTIGUOUS"] and tt.shape == v.shape
+    if starstop is None:
+        starstop = len(fs) - 1
+    nx, ny, nz = v.shape
+    return _check(_lib.lib().ttsweep_sweepXYZ(v.ctypes.data, tt.ctypes.data, nx, ny, nz,
+                                              fs.ctypes.data, starstart, starstop,
+                                              int(start[0]), int(start[1]), int(start[2])),
+                  "ttsweep_sweepXYZ")
