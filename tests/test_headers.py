@@ -1,0 +1,194 @@
+"""CPU tier: the kept C header surface (include/point3d.h, floatbox.h, velocitybox.h,
+velocityboxfiler.h).  Small C programs are compiled with gcc against the headers,
+covering what the reference's examples exercise (examples/example_floatbox.c:8-47,
+examples/example_velocityboxfiler.c:13-111) plus byte-level VBOX compatibility with
+a file written by the reference writer."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, ROOT
+
+INC = os.path.join(ROOT, "include")
+
+
+def compile_run(tmp_path, sources, args=(), cwd=None):
+    paths = []
+    for n, src in enumerate(sources):
+        p = tmp_path / f"tu{n}.c"
+        p.write_text(src)
+        paths.append(str(p))
+    exe = tmp_path / "prog"
+    r = subprocess.run(["gcc", "-std=c11", "-O2", "-Wall", "-Werror", "-I", INC, "-o", str(exe)] + paths + ["-lm"],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    r = subprocess.run([str(exe)] + list(args), capture_output=True, text=True, cwd=cwd or str(tmp_path))
+    return r
+
+
+def test_struct_layouts_and_floatbox_behaviour(tmp_path):
+    src = r"""
+#include "velocityboxfiler.h"
+#include <stddef.h>
+int main(void) {
+    struct FLOATBOX box;
+    /* layouts recorded from the reference build (SURVEY.md Appendix D) */
+    if (sizeof(struct POINT3D) != 12 || sizeof(struct FLOATBOX) != 48) return 1;
+    if (offsetof(struct FLOATBOX, size) != 24 || offsetof(struct FLOATBOX, flat) != 40) return 2;
+    if (sizeof(struct VELOCITYBOX) != 72 || offsetof(struct VELOCITYBOX, box) != 24) return 3;
+    if (sizeof(struct VBOXOPENFILE) != 56) return 4;
+    /* examples/example_floatbox.c */
+    if (!boxalloc(&box, 241, 241, 51)) return 5;
+    if (box.sx != 241u * 51u || box.sy != 51 || box.sz != 1) return 6;
+    boxput(box, 1, 2, 3, 4.567f);
+    if (boxget(box, 1, 2, 3) != 4.567f) return 7;
+    if (boxindex(box, 1, 2, 3) != 1u * 241u * 51u + 2u * 51u + 3u) return 8;
+    if (boxvolume(box) != (size_t)241 * 241 * 51) return 9;
+    boxsetall(box, 9.876f);
+    for (int x = 0; x < 241; x++) for (int y = 0; y < 241; y++) for (int z = 0; z < 51; z++)
+        if (boxget(box, x, y, z) != 9.876f) return 10;
+    boxfprint(stdout, "example: ", "\t", box);
+    boxfree(&box);
+    if (box.flat != NULL || box.size.x != 0) return 11;
+    boxinit(NULL); boxfree(NULL); vboxinit(NULL); vboxfree(NULL);
+    boxinit(&box);
+    boxsetall(box, 1.0f);               /* no storage: no-op */
+    struct VELOCITYBOX vb;
+    if (!vboxalloc(&vb, 1, 1, 1, 4, 5, 6)) return 12;
+    if (vb.max.x != 4 || vb.max.y != 5 || vb.max.z != 6 || vb.min.z != 1) return 13;
+    vboxfprint(NULL, NULL, NULL, vb);
+    vboxfree(&vb);
+    return 0;
+}
+"""
+    r = compile_run(tmp_path, [src])
+    assert r.returncode == 0, (r.returncode, r.stdout, r.stderr)
+    out = r.stdout
+    assert "example: FLOATBOX {" in out and "example: \tstrides: (12291, 51, 1)" in out
+    assert "example: \tsize: (241, 241, 51)" in out
+    assert "VELOCITYBOX {\n  minimum corner: (1, 1, 1)\n  maximum corner: (4, 5, 6)\n  FLOATBOX {" in out
+
+
+def test_headers_link_from_two_translation_units(tmp_path):
+    """The reference headers define external functions and only link from one TU
+    (SURVEY.md 8-b); the kept surface must not have that limitation."""
+    a = '#include "velocityboxfiler.h"\nint other(void);\nint main(void){ struct FLOATBOX b; boxinit(&b); return other(); }\n'
+    b = '#include "velocityboxfiler.h"\nint other(void){ struct VELOCITYBOX v; vboxinit(&v); return 0; }\n'
+    assert compile_run(tmp_path, [a, b]).returncode == 0
+
+
+VBOX_PROG = r"""
+#include "velocityboxfiler.h"
+#include <string.h>
+/* argv: mode file [file2] */
+int main(int argc, char **argv) {
+    struct VELOCITYBOX vb;
+    (void)argc;
+    if (!strcmp(argv[1], "copy")) {             /* load argv[2], store argv[3] */
+        if (!vbfileloadbinary(&vb, argv[2])) return 1;
+        printf("%d %d %d %d %d %d\n", vb.min.x, vb.min.y, vb.min.z,
+               vb.box.size.x, vb.box.size.y, vb.box.size.z);
+        if (!vbfilestorebinary(argv[3], vb)) return 2;
+        vboxfree(&vb);
+        return 0;
+    }
+    if (!strcmp(argv[1], "load")) return vbfileloadbinary(&vb, argv[2]) ? 0 : 1;
+    if (!strcmp(argv[1], "text")) {             /* text argv[2] -> vbox argv[3] (tools/vconvert.c) */
+        if (!vbfileloadtext(&vb, argv[2])) return 1;
+        printf("%d %d %d %d %d %d\n", vb.min.x, vb.min.y, vb.min.z,
+               vb.box.size.x, vb.box.size.y, vb.box.size.z);
+        return vbfilestorebinary(argv[3], vb) ? 0 : 2;
+    }
+    if (!strcmp(argv[1], "subset")) {           /* examples/example_velocityboxfiler.c:70-104 */
+        struct VBOXOPENFILE f;
+        if (!vbfileopenbinary(&f, argv[2])) return 1;
+        int ox = f.min.x + f.dims.x / 3, oy = f.min.y + f.dims.y / 3, oz = f.min.z + f.dims.z / 3;
+        int nx = f.dims.x / 3, ny = f.dims.y / 3, nz = f.dims.z / 3;
+        if (!vbfileloadbinarysubset(&vb, ox, oy, oz, nx, ny, nz, f)) return 2;
+        printf("%d %d %d %d %d %d\n", ox, oy, oz, nx, ny, nz);
+        for (int x = 0; x < nx; x++) for (int y = 0; y < ny; y++) for (int z = 0; z < nz; z++)
+            printf("%.9g\n", boxget(vb.box, x, y, z));
+        /* out-of-range request must fail */
+        struct VELOCITYBOX bad;
+        if (vbfileloadbinarysubset(&bad, f.min.x - 1, oy, oz, nx, ny, nz, f)) return 3;
+        if (vbfileloadbinarysubset(&bad, ox, oy, oz, f.dims.x, ny, nz, f)) return 4;
+        vbfileclosebinary(&f);
+        vbfileclosebinary(&f);                  /* idempotent */
+        return 0;
+    }
+    return 9;
+}
+"""
+
+
+def test_vbox_roundtrip_is_byte_identical_to_reference_writer(tmp_path):
+    ref_file = os.path.join(GOLDEN, "ref_written_6x5x4.vbox")
+    out = tmp_path / "copy.vbox"
+    r = compile_run(tmp_path, [VBOX_PROG], ["copy", ref_file, str(out)])
+    assert r.returncode == 0, r.stderr
+    assert r.stdout.split() == ["1", "1", "1", "6", "5", "4"]
+    assert out.read_bytes() == open(ref_file, "rb").read()
+
+
+def test_vbox_loader_rejects_corruption(tmp_path):
+    blob = bytearray(open(os.path.join(GOLDEN, "ref_written_6x5x4.vbox"), "rb").read())
+    cases = {}
+    b = bytearray(blob); b[50] ^= 0x40; cases["flipped"] = bytes(b)
+    cases["truncated"] = bytes(blob[:-8])
+    b = bytearray(blob); b[0] = ord("x"); cases["magic"] = bytes(b)
+    cases["empty"] = b""
+    for name, data in cases.items():
+        p = tmp_path / f"{name}.vbox"
+        p.write_bytes(data)
+        r = compile_run(tmp_path, [VBOX_PROG], ["load", str(p)])
+        assert r.returncode == 1, name
+        assert "vbfile" in r.stderr, name
+    r = compile_run(tmp_path, [VBOX_PROG], ["load", str(tmp_path / "missing.vbox")])
+    assert r.returncode == 1 and "error opening file" in r.stderr
+
+
+def test_text_loader_and_subset(tmp_path, pkg):
+    """Text format x,y,z,v (include/velocityboxfiler.h:95-103) -> VBOX, then the
+    middle-third subset of the example program."""
+    shape = (7, 6, 9)
+    v = np.round(pkg.inputs.velocity_model(*shape, seed=4), 5).astype(np.float32)
+    lines = []
+    for x in range(shape[0]):
+        for y in range(shape[1]):
+            for z in range(shape[2]):
+                lines.append(f"{x + 1},{y + 1},{z + 1},{v[x, y, z]:.5f}")
+    txt = tmp_path / "model.txt"
+    txt.write_text("\n".join(lines) + "\n")
+    vb = tmp_path / "model.vbox"
+    r = compile_run(tmp_path, [VBOX_PROG], ["text", str(txt), str(vb)])
+    assert r.returncode == 0, r.stderr
+    assert r.stdout.split() == ["1", "1", "1", "7", "6", "9"]
+    origin, got = pkg.inputs.read_vbox(str(vb))
+    want = np.array([float(l.split(",")[3]) for l in lines], dtype=np.float32).reshape(shape)
+    assert origin == (1, 1, 1) and np.array_equal(got, want)
+
+    r = compile_run(tmp_path, [VBOX_PROG], ["subset", str(vb)])
+    assert r.returncode == 0, (r.returncode, r.stderr)
+    tok = r.stdout.split()
+    ox, oy, oz, nx, ny, nz = map(int, tok[:6])
+    assert (ox, oy, oz, nx, ny, nz) == (3, 3, 4, 2, 2, 3)
+    sub = np.array(tok[6:], dtype=np.float32).reshape(nx, ny, nz)
+    # the reference pairs a GLOBAL bounds test with a 0-based file index (:760-827)
+    assert np.array_equal(sub, want[ox:ox + nx, oy:oy + ny, oz:oz + nz])
+
+
+def test_reference_reader_accepts_our_writer(tmp_path, pkg, oracle):
+    """Cross-check against the reference's own reader, where it is available."""
+    R = oracle.ref()
+    if R is None:
+        pytest.skip("reference checkout not present (GPU box)")
+    v = pkg.inputs.velocity_model(5, 4, 3, seed=9)
+    v[0, 0, 0] = -2.0
+    path = tmp_path / "ours.vbox"
+    pkg.inputs.write_vbox(str(path), v, origin=(2, 3, 4))
+    hdr = np.zeros(6, np.int32)
+    out = np.zeros(v.size, np.float32)
+    assert R.ttref_load_vbox(str(path).encode(), hdr, out, out.size) == 1
+    assert hdr.tolist() == [2, 3, 4, 5, 4, 3] and np.array_equal(out.reshape(v.shape), v)

@@ -1,0 +1,77 @@
+"""CPU tier: the N > 1 path (start sharding + gather) with world_size 2 and 3 over gloo.
+The per-rank solver is injected; here it is the CPU oracle (checker role only), so
+the test exercises exactly the sharding / gather code bench.py runs over RCCL."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from conftest import ROOT
+
+
+def free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def worker(rank, world, port, nstart, outdir):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import oracle as O
+    import ttsweep_pkg
+    P = ttsweep_pkg.load()
+    shape = (10, 9, 6)
+    v = P.inputs.velocity_model(*shape, seed=21)
+    offs = P.inputs.read_triples(P.inputs.star_path("3"))
+    fs = O.make_star(offs)
+    rng = np.random.default_rng(5)
+    starts = np.stack([rng.integers(0, n, size=nstart) for n in shape], axis=1).astype(np.int32)
+
+    def solve_fn(my_starts):
+        boxes = [O.converge(v, fs, st, order=1)[0] for st in my_starts]
+        if not boxes:
+            return torch.empty((0,) + shape, dtype=torch.float32)
+        return torch.from_numpy(np.stack(boxes))
+
+    allb, local = P.multistart.solve_sharded(starts, solve_fn, dist, dst=0)
+    assert local.shape[0] == len(P.multistart.shard_starts(nstart, world, rank))
+    if rank == 0:
+        np.save(os.path.join(outdir, "gathered.npy"), allb.numpy())
+        np.save(os.path.join(outdir, "starts.npy"), starts)
+    else:
+        assert allb is None
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,nstart", [(2, 5), (3, 4), (2, 1)])
+def test_sharded_solve_gathers_in_start_order(tmp_path, oracle, pkg, world, nstart):
+    port = free_port()
+    mp.spawn(worker, args=(world, port, nstart, str(tmp_path)), nprocs=world, join=True)
+    got = np.load(tmp_path / "gathered.npy")
+    starts = np.load(tmp_path / "starts.npy")
+    assert got.shape[0] == nstart
+    v = pkg.inputs.velocity_model(10, 9, 6, seed=21)
+    fs = oracle.make_star(pkg.inputs.read_triples(pkg.inputs.star_path("3")))
+    for s in range(nstart):
+        want, _, _ = oracle.converge(v, fs, starts[s])
+        assert np.array_equal(got[s].view(np.uint32), want.view(np.uint32)), s
+
+
+def test_shard_assignment_is_a_partition(pkg):
+    for nstart in (0, 1, 4, 24, 111):
+        for world in (1, 2, 4, 8):
+            shards = [pkg.multistart.shard_starts(nstart, world, r) for r in range(world)]
+            flat = sorted(s for sh in shards for s in sh)
+            assert flat == list(range(nstart))
+            assert pkg.multistart.shard_sizes(nstart, world) == [len(sh) for sh in shards]
+            assert max(map(len, shards)) - min(map(len, shards)) <= 1

@@ -75,6 +75,35 @@ def build(verbose: bool = False) -> str:
 _lib = None
 
 
+def _load_hip_runtime():
+    """libttsweep.so is linked without a HIP runtime of its own (-no-hip-rt): make
+    one visible (RTLD_GLOBAL) before loading it.  When PyTorch is installed its
+    bundled libamdhip64 is used, so that torch (device memory, RCCL) and the sweep
+    library share ONE runtime in the process; otherwise the system ROCm one."""
+    candidates = []
+    try:
+        import importlib.util
+        spec = importlib.util.find_spec("torch")
+        if spec and spec.origin:
+            candidates.append(os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so"))
+    except Exception:
+        pass
+    rocm = os.environ.get("ROCM_PATH", "/opt/rocm")
+    candidates += [os.path.join(rocm, "lib", "libamdhip64.so"), "libamdhip64.so"]
+    errors = []
+    for path in candidates:
+        if os.path.sep in path and not os.path.exists(path):
+            continue
+        try:
+            return C.CDLL(path, mode=C.RTLD_GLOBAL)
+        except OSError as e:
+            errors.append(f"{path}: {e}")
+    raise RuntimeError("no HIP runtime (libamdhip64) could be loaded: " + "; ".join(errors))
+
+
+_hip = None
+
+
 def lib():
     """The loaded library; raises if it has not been built (no fallback)."""
     global _lib
@@ -83,6 +112,8 @@ def lib():
             raise RuntimeError(
                 f"{LIB_PATH} is missing: run __graft_entry__.build() (hipcc) first; "
                 "there is no CPU fallback for the sweep")
+        global _hip
+        _hip = _load_hip_runtime()
         L = C.CDLL(LIB_PATH)
         for name, res, args in SYMBOLS:
             fn = getattr(L, name)       # AttributeError if the symbol is not exported
