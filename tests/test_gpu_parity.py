@@ -39,14 +39,19 @@ def gpu_converge(P, v, fs, starts, starstart=0, starstop=None, tts=None, kernel=
         return tts, rc, sol.stats()
 
 
-def test_golden_cases_bit_exact(P, golden):
+KERNELS = [pytest.param(1, id="cell"), pytest.param(2, id="strip")]
+
+
+@pytest.mark.parametrize("kernel", KERNELS)
+def test_golden_cases_bit_exact(P, golden, kernel):
     """Every fixture: 5 stars (3 shipped, one non-symmetric, 6-neighbour) x 4 start
-    kinds (interior, corner, dead edge inside / outside the grid)."""
+    kinds (interior, corner, dead edge inside / outside the grid), both kernels."""
     n = 0
     for key, sname, offs, start, want, _ in golden.cases():
         fs = P.inputs.make_fs(offs)
-        (tt,), rc, st = gpu_converge(P, golden.v, fs, [start])
+        (tt,), rc, st = gpu_converge(P, golden.v, fs, [start], kernel=kernel)
         assert rc == 1, key
+        assert st["kernel_variant"] == kernel
         assert_bit_equal(tt, want, key)
         assert st["sweeps_total"] >= 2
         n += 1
@@ -103,7 +108,8 @@ def test_sweepXYZ_dropin(P, golden24):
 
 @pytest.mark.parametrize("shape,seed", [((33, 70, 19), 11), ((70, 33, 40), 12), ((5, 4, 3), 13),
                                         ((1, 1, 1), 14), ((2, 300, 2), 15), ((130, 3, 66), 16)])
-def test_seeded_random_vs_oracle(P, oracle, shape, seed):
+@pytest.mark.parametrize("kernel", KERNELS)
+def test_seeded_random_vs_oracle(P, oracle, shape, seed, kernel):
     """Ragged / tiny / thin grids (smaller than the star radius on some axes) with
     random velocities and a random asymmetric star, against the CPU oracle."""
     rng = np.random.default_rng(seed)
@@ -112,8 +118,23 @@ def test_seeded_random_vs_oracle(P, oracle, shape, seed):
     offs = offs[np.any(offs != 0, axis=1)]
     start = [int(rng.integers(0, n)) for n in shape]
     want, _, _ = oracle.converge(v, oracle.make_star(offs), start, order=1)
-    (tt,), _, _ = gpu_converge(P, v, P.inputs.make_fs(offs), [start])
+    (tt,), _, st = gpu_converge(P, v, P.inputs.make_fs(offs), [start], kernel=kernel)
+    assert st["kernel_variant"] == kernel
     assert_bit_equal(tt, want, str(shape))
+
+
+def test_large_radius_star_falls_back_to_cell_kernel(P, oracle):
+    """Offsets beyond +-7 (FSRADIUSMAX, serial_new/...:41) are outside the STRIP
+    kernel's window; the library must still solve them (CELL kernel)."""
+    rng = np.random.default_rng(99)
+    shape = (20, 30, 25)
+    v = rng.uniform(0.1, 0.5, size=shape).astype(np.float32)
+    offs = np.array([[9, 0, 0], [0, -10, 1], [1, 1, 8], [-1, 0, 0], [0, 0, 1], [2, 2, 2]], np.int32)
+    start = (3, 4, 5)
+    want, _, _ = oracle.converge(v, oracle.make_star(offs), start, order=1)
+    (tt,), _, st = gpu_converge(P, v, P.inputs.make_fs(offs), [start])
+    assert st["kernel_variant"] == 1
+    assert_bit_equal(tt, want, "radius 10")
 
 
 def test_device_resident_solve(P, golden24):

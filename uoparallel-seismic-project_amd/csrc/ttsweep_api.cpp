@@ -8,6 +8,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <array>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -67,6 +68,13 @@ struct ttsweep_ctx {
     CellEntry *d_cell_entries = nullptr;
     int n_cell_entries = 0;
 
+    // STRIP kernel: (da, db) columns of the star, dead-edge boxes
+    StripCol *d_strip_cols = nullptr;
+    StripPlan plan{};
+    std::vector<std::array<int, 3>> special_offsets;   // device-axis offsets e: cell start - e owns a dead edge
+    bool start_is_special = false;
+    int max_box_cells = 0;                  // of the current solve
+
     // per-solve pools (grown on demand, reused between solves)
     float *d_T = nullptr;                   // capacity_starts padded volumes
     int capacity_starts = 0;
@@ -113,6 +121,122 @@ static void make_layout_cell(ttsweep_ctx *ctx)
     L.cells = L.s0 * L.p[0];
 }
 
+// Padded layout for the STRIP kernel.  The axis with the worst 64-cell tile
+// utilisation becomes the plane axis a (it is not tiled); the stride-1 axis c
+// gets the strips, b the lanes.
+static void make_layout_strip(ttsweep_ctx *ctx)
+{
+    DevLayout &L = ctx->L;
+    const int n[3] = {ctx->nx, ctx->ny, ctx->nz};
+    auto util = [](int m) { return (double)m / (double)(((m + 63) / 64) * 64); };
+    int worst = 0;
+    for (int d = 1; d < 3; d++)
+        if (util(n[d]) < util(n[worst]) - 1e-12) worst = d;
+    int rest[2], k = 0;
+    for (int d = 0; d < 3; d++)
+        if (d != worst) rest[k++] = d;
+    L.perm[0] = worst;
+    L.perm[1] = rest[0];
+    L.perm[2] = rest[1];
+    int r[3] = {0, 0, 0};
+    for (const auto &e : ctx->pull) {
+        const int u[3] = {e.di, e.dj, e.dk};
+        for (int d = 0; d < 3; d++) r[d] = std::max(r[d], std::abs(u[L.perm[d]]));
+    }
+    for (int d = 0; d < 3; d++) {
+        L.n[d] = n[L.perm[d]];
+        L.un[d] = n[d];
+    }
+    L.lo[0] = std::max(r[0], 1);
+    L.p[0] = L.n[0] + 2 * L.lo[0];
+    L.lo[1] = std::max(r[1], 1);
+    L.p[1] = ((L.n[1] + STRIP_TB - 1) / STRIP_TB) * STRIP_TB + 2 * L.lo[1];
+    L.lo[2] = STRIP_CF;
+    L.p[2] = ((L.n[2] + STRIP_TC - 1) / STRIP_TC) * STRIP_TC + 2 * STRIP_CF;
+    L.s1 = L.p[2];
+    L.s0 = (long long)L.p[1] * L.p[2];
+    L.cells = L.s0 * L.p[0];
+    ctx->plan.ra = r[0];
+    ctx->plan.rb = L.lo[1];
+}
+
+// Can the STRIP kernel handle this star?  (plane and strip offsets within +-7)
+static bool strip_supported(const ttsweep_ctx *ctx)
+{
+    return !ctx->pull.empty() && ctx->radius <= STRIP_MAX_RA && ctx->radius < STRIP_CF;
+}
+
+static int upload_strip_plan(ttsweep_ctx *ctx)
+{
+    const DevLayout &L = ctx->L;
+    StripPlan &plan = ctx->plan;
+    struct Key { int da, db; };
+    std::vector<std::vector<StripCol>> per_plane(2 * plan.ra + 1);
+    ctx->special_offsets.clear();
+    ctx->start_is_special = false;
+    for (const auto &e : ctx->pull) {
+        const int u[3] = {e.di, e.dj, e.dk};
+        const int da = u[L.perm[0]], db = u[L.perm[1]], dc = u[L.perm[2]];
+        if (e.flags == PULL_FWD) ctx->start_is_special = true;              // dead when the centre is the start
+        if (e.flags == PULL_REV) ctx->special_offsets.push_back({da, db, dc});   // dead when the neighbour is the start
+        std::vector<StripCol> &cols = per_plane[da + plan.ra];
+        const int t = dc + STRIP_CF;
+        StripCol *col = nullptr;
+        for (auto &c : cols)
+            if (c.rowoff == db && !(c.mask & (1u << t))) { col = &c; break; }
+        if (!col) {     // (a second column for the same (da,db) only if an offset repeats with another length)
+            cols.push_back(StripCol{});
+            col = &cols.back();
+            col->rowoff = db;
+        }
+        col->mask |= 1u << t;
+        col->h[t] = e.h;
+        for (int j = 0; j < STRIP_W / 4; j++)      // window floats t .. t+K-1 are read
+            if (4 * j + 3 >= t && 4 * j <= t + STRIP_K - 1) col->chunks |= 1u << j;
+    }
+    std::vector<StripCol> flat;
+    for (int ia = 0; ia <= 2 * plan.ra; ia++) {
+        plan.first[ia] = (int)flat.size();
+        flat.insert(flat.end(), per_plane[ia].begin(), per_plane[ia].end());
+    }
+    plan.first[2 * plan.ra + 1] = (int)flat.size();
+    if (ctx->d_strip_cols) HIPCHK(hipFree(ctx->d_strip_cols));
+    ctx->d_strip_cols = nullptr;
+    if (!flat.empty()) {
+        HIPCHK(hipMalloc((void **)&ctx->d_strip_cols, flat.size() * sizeof(StripCol)));
+        HIPCHK(hipMemcpy(ctx->d_strip_cols, flat.data(), flat.size() * sizeof(StripCol),
+                         hipMemcpyHostToDevice));
+    }
+    return 0;
+}
+
+// Dead-edge box of one start (device axes, clipped, inclusive).
+static void fill_special_box(const ttsweep_ctx *ctx, StartDesc &sd)
+{
+    const DevLayout &L = ctx->L;
+    const int st[3] = {sd.sa, sd.sb, sd.sc};
+    int lo[3] = {1, 1, 1}, hi[3] = {0, 0, 0};
+    bool any = false;
+    auto add = [&](const int p[3]) {
+        for (int d = 0; d < 3; d++)
+            if (p[d] < 0 || p[d] >= L.n[d]) return;
+        for (int d = 0; d < 3; d++) {
+            lo[d] = any ? std::min(lo[d], p[d]) : p[d];
+            hi[d] = any ? std::max(hi[d], p[d]) : p[d];
+        }
+        any = true;
+    };
+    if (ctx->start_is_special) add(st);
+    for (const auto &e : ctx->special_offsets) {
+        const int p[3] = {st[0] - e[0], st[1] - e[1], st[2] - e[2]};
+        add(p);
+    }
+    for (int d = 0; d < 3; d++) {
+        sd.box_lo[d] = lo[d];
+        sd.box_hi[d] = hi[d];
+    }
+}
+
 static int upload_star(ttsweep_ctx *ctx)
 {
     const DevLayout &L = ctx->L;
@@ -145,7 +269,8 @@ static int upload_star(ttsweep_ctx *ctx)
 
 static int ensure_capacity(ttsweep_ctx *ctx, int nstart)
 {
-    if (nstart <= ctx->capacity_starts) return 0;
+    if (nstart <= ctx->capacity_starts && ctx->d_T) return 0;
+    nstart = std::max(nstart, ctx->capacity_starts);
     if (ctx->d_T) HIPCHK(hipFree(ctx->d_T));
     if (ctx->d_starts) HIPCHK(hipFree(ctx->d_starts));
     if (ctx->d_active) HIPCHK(hipFree(ctx->d_active));
@@ -184,9 +309,17 @@ static int launch_pass(ttsweep_ctx *ctx, int nactive)
 {
     hipEvent_t e0, e1;
     if (ctx->timing && timed_event(ctx, &e0)) return -1;
-    HIPCHK(launch_sweep_cell(ctx->L, ctx->d_v, ctx->d_starts, ctx->d_active, nactive,
-                             ctx->d_changed, ctx->d_cell_entries, ctx->n_cell_entries,
-                             ctx->stream));
+    if (ctx->kernel == TTSWEEP_KERNEL_STRIP) {
+        HIPCHK(launch_sweep_strip(ctx->L, ctx->d_v, ctx->d_starts, ctx->d_active, nactive,
+                                  ctx->d_changed, ctx->d_strip_cols, ctx->plan, ctx->stream));
+        HIPCHK(launch_sweep_special(ctx->L, ctx->d_v, ctx->d_starts, ctx->d_active, nactive,
+                                    ctx->d_changed, ctx->d_cell_entries, ctx->n_cell_entries,
+                                    ctx->max_box_cells, ctx->stream));
+    } else {
+        HIPCHK(launch_sweep_cell(ctx->L, ctx->d_v, ctx->d_starts, ctx->d_active, nactive,
+                                 ctx->d_changed, ctx->d_cell_entries, ctx->n_cell_entries,
+                                 ctx->stream));
+    }
     if (ctx->timing && timed_event(ctx, &e1)) return -1;
     ctx->stats.launches++;
     return 0;
@@ -253,7 +386,13 @@ ttsweep_ctx *ttsweep_create(int device, int nx, int ny, int nz, const ttsweep_fs
     ctx->pull = build_pull_star(fs, starstart, starstop);
     ctx->radius = pull_star_radius(ctx->pull);
     ctx->relax_per_sweep = ttsweep_relaxations_per_sweep(nx, ny, nz, fs, starstart, starstop);
-    make_layout_cell(ctx);
+    ctx->kernel = strip_supported(ctx) ? TTSWEEP_KERNEL_STRIP : TTSWEEP_KERNEL_CELL;
+    if (const char *env = getenv("TTSWEEP_KERNEL")) {
+        const int k = atoi(env);
+        if (k == TTSWEEP_KERNEL_CELL || (k == TTSWEEP_KERNEL_STRIP && strip_supported(ctx))) ctx->kernel = k;
+    }
+    if (ctx->kernel == TTSWEEP_KERNEL_STRIP) make_layout_strip(ctx);
+    else make_layout_cell(ctx);
 
     bool ok = hipSetDevice(device) == hipSuccess
            && hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) == hipSuccess
@@ -265,7 +404,7 @@ ttsweep_ctx *ttsweep_create(int device, int nx, int ny, int nz, const ttsweep_fs
         ttsweep_destroy(ctx);
         return nullptr;
     }
-    if (upload_star(ctx)) {
+    if (upload_star(ctx) || (ctx->kernel == TTSWEEP_KERNEL_STRIP && upload_strip_plan(ctx))) {
         ttsweep_destroy(ctx);
         return nullptr;
     }
@@ -279,6 +418,7 @@ void ttsweep_destroy(ttsweep_ctx *ctx)
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     (void)hipFree(ctx->d_v);
     (void)hipFree(ctx->d_cell_entries);
+    (void)hipFree(ctx->d_strip_cols);
     (void)hipFree(ctx->d_T);
     (void)hipFree(ctx->d_starts);
     (void)hipFree(ctx->d_active);
@@ -298,11 +438,29 @@ int ttsweep_set_option(ttsweep_ctx *ctx, int key, long long value)
     if (!ctx) return set_error("null context");
     switch (key) {
     case TTSWEEP_OPT_TIMING: ctx->timing = value != 0; return 0;
-    case TTSWEEP_OPT_KERNEL:
-        if (value != TTSWEEP_KERNEL_AUTO && value != TTSWEEP_KERNEL_CELL)
-            return set_error("kernel variant %lld not available", value);
-        ctx->forced_kernel = (int)value;
+    case TTSWEEP_OPT_KERNEL: {
+        int k = (int)value;
+        if (k == TTSWEEP_KERNEL_AUTO) k = strip_supported(ctx) ? TTSWEEP_KERNEL_STRIP : TTSWEEP_KERNEL_CELL;
+        if (k != TTSWEEP_KERNEL_CELL && !(k == TTSWEEP_KERNEL_STRIP && strip_supported(ctx)))
+            return set_error("kernel variant %lld not available for this star", value);
+        if (k == ctx->kernel) return 0;
+        // the padded layout depends on the kernel: rebuild it and drop device copies
+        if (ctx_bind(ctx)) return -1;
+        HIPCHK(hipStreamSynchronize(ctx->stream));
+        ctx->kernel = k;
+        if (k == TTSWEEP_KERNEL_STRIP) make_layout_strip(ctx);
+        else make_layout_cell(ctx);
+        HIPCHK(hipFree(ctx->d_v));
+        ctx->d_v = nullptr;
+        ctx->have_v = false;
+        if (ctx->d_T) HIPCHK(hipFree(ctx->d_T));
+        ctx->d_T = nullptr;
+        ctx->capacity_starts = 0;
+        HIPCHK(hipMalloc((void **)&ctx->d_v, (size_t)ctx->L.cells * sizeof(float)));
+        if (upload_star(ctx)) return -1;
+        if (k == TTSWEEP_KERNEL_STRIP && upload_strip_plan(ctx)) return -1;
         return 0;
+    }
     case TTSWEEP_OPT_MAX_SWEEPS:
         if (value <= 0) return set_error("max sweeps must be positive");
         ctx->max_sweeps = value;
@@ -370,6 +528,12 @@ int ttsweep_solve_device(ttsweep_ctx *ctx, int nstart, const ttsweep_start *star
         sd.sc = u[L.perm[2]];
         sd.sidx = dev_index(L, sd.sa, sd.sb, sd.sc);
         sd.pad_ = 0;
+        fill_special_box(ctx, sd);
+        {
+            long long vol = 1;
+            for (int d = 0; d < 3; d++) vol *= std::max(sd.box_hi[d] - sd.box_lo[d] + 1, 0);
+            ctx->max_box_cells = std::max<long long>(s == 0 ? 0 : ctx->max_box_cells, vol);
+        }
         if (init) HIPCHK(launch_init_tt(L, sd.T, sd.sidx, ctx->stream));
         else HIPCHK(launch_pack(L, tt_dev[s], sd.T, INFINITY, ctx->stream));
         ctx->h_active[s] = s;

@@ -51,6 +51,39 @@ struct StartDesc {
     long long sidx;         // padded linear index of the start cell
     int sa, sb, sc;         // start cell, device-axis interior coordinates
     int pad_;
+    // Bounding box (inclusive, device axes, clipped to the grid) of the cells
+    // that have at least one dead edge: the STRIP kernel does not store into
+    // them, the exact wave-per-cell kernel owns them.  Empty if lo > hi.
+    int box_lo[3], box_hi[3];
+};
+
+// ---------------------------------------------------------------------------
+// STRIP kernel geometry (compile-time)
+// ---------------------------------------------------------------------------
+constexpr int STRIP_K = 16;                         // cells per thread along c
+constexpr int STRIP_NS = 4;                         // strips (= waves) per workgroup
+constexpr int STRIP_TB = 64;                        // lanes along b
+constexpr int STRIP_CF = 8;                         // halo in front of a strip window (>= max|dc|, multiple of 4)
+constexpr int STRIP_W = STRIP_K + 2 * STRIP_CF;     // neighbour window per (cell strip, column)
+constexpr int STRIP_TC = STRIP_K * STRIP_NS;        // tile extent along c
+constexpr int STRIP_PWV = STRIP_TC + 2 * STRIP_CF;  // valid floats per slab row
+// slab row pitch: PW/4 must be odd so that 16 lanes reading float4 at a stride
+// of one row hit 64 distinct banks (MI355X_MICROARCH.md, LDS ds_read_b128)
+constexpr int STRIP_PW = STRIP_PWV + (((STRIP_PWV / 4) % 2 == 0) ? 4 : 0);
+constexpr int STRIP_MAX_RA = 7;                     // plane offsets handled: |da| <= 7
+
+// One (da, db) column of the pull star: all offsets that differ only in dc.
+struct StripCol {
+    int rowoff;             // db: row offset inside the staged slab
+    unsigned mask;          // bit t (1..15) set: offset dc = t - 8 is present
+    unsigned chunks;        // bit j set: float4 j of the window is needed
+    int pad_;
+    float h[16];            // h[t] = d/2 of offset (da, db, t-8)
+};
+
+struct StripPlan {
+    int ra, rb;                         // max |da|, max |db| over the star
+    int first[2 * STRIP_MAX_RA + 2];    // columns of plane offset da are [first[da+ra], first[da+ra+1])
 };
 
 } // namespace ttsweep

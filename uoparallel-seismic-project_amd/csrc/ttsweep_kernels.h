@@ -25,4 +25,17 @@ hipError_t launch_sweep_cell(const DevLayout &L, const float *v, const StartDesc
                              const int *active, int nactive, int *changed,
                              const CellEntry *entries, int nentries, hipStream_t st);
 
+// ---- sweep, variant STRIP --------------------------------------------------
+// Same contract as launch_sweep_cell, but cells inside a start's dead-edge box
+// (StartDesc::box_*) are left untouched; launch_sweep_special relaxes exactly
+// those cells with the full liveness rule.
+size_t strip_lds_bytes(const StripPlan &plan);
+hipError_t launch_sweep_strip(const DevLayout &L, const float *v, const StartDesc *starts,
+                              const int *active, int nactive, int *changed,
+                              const StripCol *cols, const StripPlan &plan, hipStream_t st);
+hipError_t launch_sweep_special(const DevLayout &L, const float *v, const StartDesc *starts,
+                                const int *active, int nactive, int *changed,
+                                const CellEntry *entries, int nentries, int max_box_cells,
+                                hipStream_t st);
+
 } // namespace ttsweep

@@ -177,4 +177,236 @@ hipError_t launch_sweep_cell(const DevLayout &L, const float *v, const StartDesc
     return hipGetLastError();
 }
 
+
+// ===========================================================================
+// sweep, variant STRIP: LDS-staged neighbour planes, register strips
+// ===========================================================================
+//
+// Work decomposition (device axes a, b, c; c is stride-1):
+//   workgroup = one plane a x 64 cells along b x STRIP_TC cells along c
+//   wave      = 64 lanes along b, one strip of STRIP_K consecutive c cells per lane
+// Each lane keeps acc[K] (best travel time so far) and vc[K] (own velocities) in
+// registers.  For every plane offset da the workgroup stages the neighbour
+// plane's (64 + 2 rb) x (TC + 16) window of v and T into LDS once; then for
+// every (da, db) column of the star a lane reads ONE register window of
+// K + 16 neighbour values (8 ds_read_b128 per array, conflict-free by the odd
+// row pitch) and relaxes all offsets dc of that column against it: each
+// loaded value is reused for up to 15 offsets, which is what keeps the kernel
+// VALU-bound instead of LDS-bound ("STRIP kernel").
+//
+// The relaxation is branch-free: there are no bounds tests (halo cells hold
+// +INF / 0) and no liveness tests.  The few cells that own a dead edge (inside
+// StartDesc::box) are computed but not stored; sweep_special_kernel owns them.
+
+template <int K>
+__global__ void __launch_bounds__(STRIP_TB *STRIP_NS, 3)
+sweep_strip_kernel(DevLayout L, const float *__restrict__ v,
+                   const StartDesc *__restrict__ starts, const int *__restrict__ active,
+                   int *__restrict__ changed, const StripCol *__restrict__ cols,
+                   StripPlan plan, int btiles, int ctiles, unsigned nblocks)
+{
+    static_assert(K == STRIP_K, "geometry constants assume K == STRIP_K");
+    constexpr int W = K + 2 * STRIP_CF;
+    constexpr int NT = STRIP_TB * STRIP_NS;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+
+    // XCD-aware block order: blocks b and b+8 share an XCD (and its L2); give each
+    // XCD a contiguous run of logical tiles, with the plane index fastest, so the
+    // 2*ra+1 planes a tile stages are mostly L2 hits left by its predecessor.
+    unsigned bid = blockIdx.x;
+    {
+        const unsigned per = nblocks / 8;
+        if (bid < per * 8) bid = (bid % 8) * per + bid / 8;
+    }
+    const int a = bid % L.n[0];   bid /= L.n[0];
+    const int ct = bid % ctiles;  bid /= ctiles;
+    const int bt = bid % btiles;  bid /= btiles;
+    const int s = active[bid];
+
+    const int lane = threadIdx.x;
+    const int strip = threadIdx.y;
+    const int tid = strip * STRIP_TB + lane;
+    const int b0 = bt * STRIP_TB;
+    const int c0 = ct * STRIP_TC;
+    const int rb = plan.rb;
+    const int rows = STRIP_TB + 2 * rb;
+
+    const StartDesc sd = starts[s];
+    float *__restrict__ T = sd.T;
+
+    float *sv = smem;
+    float *sT = smem + rows * STRIP_PW;
+
+    // own cells: (a, b0 + lane, c0 + strip*K + q)
+    const long long own = (long long)(a + L.lo[0]) * L.s0 + (long long)(b0 + lane + L.lo[1]) * L.s1
+                        + (c0 + strip * K + L.lo[2]);
+    float vc[K], acc[K];
+#pragma unroll
+    for (int j = 0; j < K / 4; j++) {
+        const float4 x = *reinterpret_cast<const float4 *>(v + own + 4 * j);
+        const float4 y = *reinterpret_cast<const float4 *>(T + own + 4 * j);
+        vc[4 * j + 0] = x.x; vc[4 * j + 1] = x.y; vc[4 * j + 2] = x.z; vc[4 * j + 3] = x.w;
+        acc[4 * j + 0] = y.x; acc[4 * j + 1] = y.y; acc[4 * j + 2] = y.z; acc[4 * j + 3] = y.w;
+    }
+
+    constexpr int F4_PER_ROW = STRIP_PWV / 4;
+    const int nf4 = rows * F4_PER_ROW;
+
+    for (int ia = 0; ia <= 2 * plan.ra; ia++) {
+        const int cbeg = plan.first[ia], cend = plan.first[ia + 1];
+        if (cbeg == cend) continue;
+        const int da = ia - plan.ra;
+
+        // ---- stage plane a+da: rows b0-rb .. b0+63+rb, columns c0-CF .. c0+TC+CF-1
+        const long long src = (long long)(a + da + L.lo[0]) * L.s0
+                            + (long long)(b0 - rb + L.lo[1]) * L.s1 + (c0 - STRIP_CF + L.lo[2]);
+        __syncthreads();            // everybody is done reading the previous slab
+        for (int f = tid; f < nf4; f += NT) {
+            const int r = f / F4_PER_ROW;
+            const int c4 = f - r * F4_PER_ROW;
+            const long long g = src + (long long)r * L.s1 + 4 * c4;
+            const float4 xv = *reinterpret_cast<const float4 *>(v + g);
+            const float4 xt = *reinterpret_cast<const float4 *>(T + g);
+            *reinterpret_cast<float4 *>(sv + r * STRIP_PW + 4 * c4) = xv;
+            *reinterpret_cast<float4 *>(sT + r * STRIP_PW + 4 * c4) = xt;
+        }
+        __syncthreads();
+
+        // ---- relax every column of this plane offset
+        for (int ci = cbeg; ci < cend; ci++) {
+            const StripCol &col = cols[ci];
+            const int off = (lane + rb + col.rowoff) * STRIP_PW + strip * K;
+            const unsigned chunks = col.chunks;
+            const unsigned mask = col.mask;
+            float vN[W], tN[W];
+#pragma unroll
+            for (int j = 0; j < W / 4; j++) {
+                if (chunks & (1u << j)) {
+                    const float4 x = *reinterpret_cast<const float4 *>(sv + off + 4 * j);
+                    const float4 y = *reinterpret_cast<const float4 *>(sT + off + 4 * j);
+                    vN[4 * j + 0] = x.x; vN[4 * j + 1] = x.y; vN[4 * j + 2] = x.z; vN[4 * j + 3] = x.w;
+                    tN[4 * j + 0] = y.x; tN[4 * j + 1] = y.y; tN[4 * j + 2] = y.z; tN[4 * j + 3] = y.w;
+                }
+            }
+#pragma unroll
+            for (int t = 1; t < 2 * STRIP_CF; t++) {
+                if (mask & (1u << t)) {
+                    const float h = col.h[t];
+#pragma unroll
+                    for (int q = 0; q < K; q++) {
+                        const float sum = vc[q] + vN[q + t];
+                        const float delay = h * sum;
+                        const float cand = delay + tN[q + t];
+                        acc[q] = fminf(acc[q], cand);
+                    }
+                }
+            }
+        }
+    }
+
+    // ---- epilogue: store improved cells that lie inside the grid and outside the
+    // dead-edge box of this start
+    const int b = b0 + lane;
+    const int cbase = c0 + strip * K;
+    const bool row_ok = b < L.n[1];
+    const bool in_box_ab = a >= sd.box_lo[0] && a <= sd.box_hi[0] && b >= sd.box_lo[1] && b <= sd.box_hi[1];
+    bool improved = false;
+#pragma unroll
+    for (int q = 0; q < K; q++) {
+        const int c = cbase + q;
+        const bool special = in_box_ab && c >= sd.box_lo[2] && c <= sd.box_hi[2];
+        if (row_ok && c < L.n[2] && !special && acc[q] < T[own + q]) {
+            T[own + q] = acc[q];
+            improved = true;
+        }
+    }
+    if (__ballot(improved) != 0ull && lane == 0) atomicOr(&changed[s], 1);
+}
+
+size_t strip_lds_bytes(const StripPlan &plan)
+{
+    return (size_t)2 * (STRIP_TB + 2 * plan.rb) * STRIP_PW * sizeof(float);
+}
+
+hipError_t launch_sweep_strip(const DevLayout &L, const float *v, const StartDesc *starts,
+                              const int *active, int nactive, int *changed,
+                              const StripCol *cols, const StripPlan &plan, hipStream_t st)
+{
+    const int btiles = (L.n[1] + STRIP_TB - 1) / STRIP_TB;
+    const int ctiles = (L.n[2] + STRIP_TC - 1) / STRIP_TC;
+    const long long nblocks = (long long)nactive * L.n[0] * btiles * ctiles;
+    if (nblocks <= 0) return hipSuccess;
+    if (nblocks > 0x7fffffffLL) return hipErrorInvalidValue;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(sweep_strip_kernel<STRIP_K>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(sweep_strip_kernel<STRIP_K>, dim3((unsigned)nblocks),
+                       dim3(STRIP_TB, STRIP_NS), strip_lds_bytes(plan), st, L, v, starts, active,
+                       changed, cols, plan, btiles, ctiles, (unsigned)nblocks);
+    return hipGetLastError();
+}
+
+// ===========================================================================
+// exact relaxation of the few cells that own a dead edge: one wave per cell
+// ===========================================================================
+// Lanes split the pull entries, apply the full liveness rule, and reduce their
+// minima across the wave.  Same in-place, single-writer contract as the other
+// kernels: only this kernel ever stores into the cells of a start's box.
+
+__global__ void __launch_bounds__(64)
+sweep_special_kernel(DevLayout L, const float *__restrict__ v,
+                     const StartDesc *__restrict__ starts, const int *__restrict__ active,
+                     int *__restrict__ changed, const CellEntry *__restrict__ entries,
+                     int nentries, int max_box_cells)
+{
+    const int s = active[blockIdx.x / max_box_cells];
+    int cell = blockIdx.x % max_box_cells;
+    const StartDesc sd = starts[s];
+    const int ea = sd.box_hi[0] - sd.box_lo[0] + 1;
+    const int eb = sd.box_hi[1] - sd.box_lo[1] + 1;
+    const int ec = sd.box_hi[2] - sd.box_lo[2] + 1;
+    if (ea <= 0 || eb <= 0 || ec <= 0 || cell >= ea * eb * ec) return;
+    const int c = sd.box_lo[2] + cell % ec; cell /= ec;
+    const int b = sd.box_lo[1] + cell % eb; cell /= eb;
+    const int a = sd.box_lo[0] + cell;
+
+    float *__restrict__ T = sd.T;
+    const long long ci = dev_index(L, a, b, c);
+    const bool c_is_start = (ci == sd.sidx);
+    const float vc = v[ci];
+    const float told = T[ci];
+    float best = told;
+    for (int e = threadIdx.x; e < nentries; e += 64) {
+        const CellEntry en = entries[e];
+        const long long oi = ci + en.delta;
+        const bool live = ((en.flags & PULL_FWD) && !c_is_start)
+                       || ((en.flags & PULL_REV) && oi != sd.sidx);
+        const float sum = vc + v[oi];
+        const float delay = en.h * sum;
+        const float cand = delay + T[oi];
+        if (live && cand < best) best = cand;
+    }
+#pragma unroll
+    for (int w = 32; w >= 1; w >>= 1) best = fminf(best, __shfl_xor(best, w));
+    if (threadIdx.x == 0 && best < told) {
+        T[ci] = best;
+        atomicOr(&changed[s], 1);
+    }
+}
+
+hipError_t launch_sweep_special(const DevLayout &L, const float *v, const StartDesc *starts,
+                                const int *active, int nactive, int *changed,
+                                const CellEntry *entries, int nentries, int max_box_cells,
+                                hipStream_t st)
+{
+    if (nactive <= 0 || max_box_cells <= 0) return hipSuccess;
+    hipLaunchKernelGGL(sweep_special_kernel, dim3((unsigned)(nactive * max_box_cells)), dim3(64), 0,
+                       st, L, v, starts, active, changed, entries, nentries, max_box_cells);
+    return hipGetLastError();
+}
+
 } // namespace ttsweep
