@@ -53,7 +53,11 @@ typedef struct ttsweep_start {
 typedef struct ttsweep_stats {
     int nstart;                 /* starts in the solve */
     int sweeps_max;             /* full-grid passes executed for the slowest start */
-    long long sweeps_total;     /* sum over starts of full-grid passes executed */
+    long long sweeps_total;     /* sum over starts of passes launched (a pass may skip
+                                   tiles whose inputs did not change) */
+    long long cells_relaxed;    /* cells actually relaxed against the whole star, summed
+                                   over passes and starts (= sweeps_total * cells when
+                                   nothing is skipped) */
     long long cells;            /* nx*ny*nz */
     long long relaxations_per_sweep; /* in-bounds (cell, offset) pairs one pass relaxes */
     long long launches;         /* sweep-kernel launches */

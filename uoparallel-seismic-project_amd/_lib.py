@@ -32,7 +32,8 @@ class PullEntry(C.Structure):
 
 class Stats(C.Structure):
     _fields_ = [("nstart", C.c_int), ("sweeps_max", C.c_int),
-                ("sweeps_total", C.c_longlong), ("cells", C.c_longlong),
+                ("sweeps_total", C.c_longlong), ("cells_relaxed", C.c_longlong),
+                ("cells", C.c_longlong),
                 ("relaxations_per_sweep", C.c_longlong), ("launches", C.c_longlong),
                 ("sweep_kernel_ms", C.c_double), ("solve_ms", C.c_double),
                 ("kernel_variant", C.c_int)]

@@ -74,6 +74,10 @@ struct ttsweep_ctx {
     std::vector<std::array<int, 3>> special_offsets;   // device-axis offsets e: cell start - e owns a dead edge
     bool start_is_special = false;
     int max_box_cells = 0;                  // of the current solve
+    int *d_tile_flags = nullptr;            // capacity_starts x 2 x tiles
+    unsigned long long *d_work = nullptr;   // capacity_starts
+    unsigned long long *h_work = nullptr;   // pinned
+    int pass_index = 0;
 
     // per-solve pools (grown on demand, reused between solves)
     float *d_T = nullptr;                   // capacity_starts padded volumes
@@ -278,6 +282,10 @@ static int ensure_capacity(ttsweep_ctx *ctx, int nstart)
     if (ctx->h_starts) HIPCHK(hipHostFree(ctx->h_starts));
     if (ctx->h_active) HIPCHK(hipHostFree(ctx->h_active));
     if (ctx->h_changed) HIPCHK(hipHostFree(ctx->h_changed));
+    if (ctx->d_tile_flags) HIPCHK(hipFree(ctx->d_tile_flags));
+    if (ctx->d_work) HIPCHK(hipFree(ctx->d_work));
+    if (ctx->h_work) HIPCHK(hipHostFree(ctx->h_work));
+    ctx->d_tile_flags = nullptr; ctx->d_work = nullptr; ctx->h_work = nullptr;
     ctx->d_T = nullptr; ctx->d_starts = nullptr; ctx->d_active = nullptr; ctx->d_changed = nullptr;
     ctx->h_starts = nullptr; ctx->h_active = nullptr; ctx->h_changed = nullptr;
     ctx->capacity_starts = 0;
@@ -288,6 +296,10 @@ static int ensure_capacity(ttsweep_ctx *ctx, int nstart)
     HIPCHK(hipHostMalloc((void **)&ctx->h_starts, nstart * sizeof(StartDesc)));
     HIPCHK(hipHostMalloc((void **)&ctx->h_active, nstart * sizeof(int)));
     HIPCHK(hipHostMalloc((void **)&ctx->h_changed, nstart * sizeof(int)));
+    HIPCHK(hipMalloc((void **)&ctx->d_tile_flags,
+                     (size_t)nstart * 2 * std::max(strip_tiles(ctx->L), 1) * sizeof(int)));
+    HIPCHK(hipMalloc((void **)&ctx->d_work, nstart * sizeof(unsigned long long)));
+    HIPCHK(hipHostMalloc((void **)&ctx->h_work, nstart * sizeof(unsigned long long)));
     ctx->capacity_starts = nstart;
     return 0;
 }
@@ -311,10 +323,11 @@ static int launch_pass(ttsweep_ctx *ctx, int nactive)
     if (ctx->timing && timed_event(ctx, &e0)) return -1;
     if (ctx->kernel == TTSWEEP_KERNEL_STRIP) {
         HIPCHK(launch_sweep_strip(ctx->L, ctx->d_v, ctx->d_starts, ctx->d_active, nactive,
-                                  ctx->d_changed, ctx->d_strip_cols, ctx->plan, ctx->stream));
+                                  ctx->d_changed, ctx->d_strip_cols, ctx->plan,
+                                  ctx->pass_index & 1, ctx->stream));
         HIPCHK(launch_sweep_special(ctx->L, ctx->d_v, ctx->d_starts, ctx->d_active, nactive,
                                     ctx->d_changed, ctx->d_cell_entries, ctx->n_cell_entries,
-                                    ctx->max_box_cells, ctx->stream));
+                                    ctx->max_box_cells, ctx->pass_index & 1, ctx->stream));
     } else {
         HIPCHK(launch_sweep_cell(ctx->L, ctx->d_v, ctx->d_starts, ctx->d_active, nactive,
                                  ctx->d_changed, ctx->d_cell_entries, ctx->n_cell_entries,
@@ -322,6 +335,7 @@ static int launch_pass(ttsweep_ctx *ctx, int nactive)
     }
     if (ctx->timing && timed_event(ctx, &e1)) return -1;
     ctx->stats.launches++;
+    ctx->pass_index++;
     return 0;
 }
 
@@ -423,6 +437,9 @@ void ttsweep_destroy(ttsweep_ctx *ctx)
     (void)hipFree(ctx->d_starts);
     (void)hipFree(ctx->d_active);
     (void)hipFree(ctx->d_changed);
+    (void)hipFree(ctx->d_tile_flags);
+    (void)hipFree(ctx->d_work);
+    if (ctx->h_work) (void)hipHostFree(ctx->h_work);
     if (ctx->h_starts) (void)hipHostFree(ctx->h_starts);
     if (ctx->h_active) (void)hipHostFree(ctx->h_active);
     if (ctx->h_changed) (void)hipHostFree(ctx->h_changed);
@@ -534,14 +551,20 @@ int ttsweep_solve_device(ttsweep_ctx *ctx, int nstart, const ttsweep_start *star
             for (int d = 0; d < 3; d++) vol *= std::max(sd.box_hi[d] - sd.box_lo[d] + 1, 0);
             ctx->max_box_cells = std::max<long long>(s == 0 ? 0 : ctx->max_box_cells, vol);
         }
+        sd.tile_flags = ctx->d_tile_flags + (size_t)s * 2 * std::max(strip_tiles(L), 1);
+        sd.work = ctx->d_work + s;
         if (init) HIPCHK(launch_init_tt(L, sd.T, sd.sidx, ctx->stream));
         else HIPCHK(launch_pack(L, tt_dev[s], sd.T, INFINITY, ctx->stream));
+        if (ctx->kernel == TTSWEEP_KERNEL_STRIP)
+            HIPCHK(launch_init_tile_flags(L, sd, /*all_active=*/!init, ctx->stream));
         ctx->h_active[s] = s;
     }
     HIPCHK(hipMemcpyAsync(ctx->d_starts, ctx->h_starts, nstart * sizeof(StartDesc),
                           hipMemcpyHostToDevice, ctx->stream));
     HIPCHK(hipMemcpyAsync(ctx->d_active, ctx->h_active, nstart * sizeof(int),
                           hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(hipMemsetAsync(ctx->d_work, 0, nstart * sizeof(unsigned long long), ctx->stream));
+    ctx->pass_index = 0;
 
     // driver loop: serial_new/...:151-170 without the break (:168-169)
     std::vector<int> sweeps(nstart, 0);
@@ -572,6 +595,8 @@ int ttsweep_solve_device(ttsweep_ctx *ctx, int nstart, const ttsweep_start *star
 
     for (int s = 0; s < nstart; s++)
         HIPCHK(launch_unpack(L, ctx->h_starts[s].T, tt_dev[s], ctx->stream));
+    HIPCHK(hipMemcpyAsync(ctx->h_work, ctx->d_work, nstart * sizeof(unsigned long long),
+                          hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipEventRecord(ctx->ev_solve1, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
 
@@ -585,6 +610,9 @@ int ttsweep_solve_device(ttsweep_ctx *ctx, int nstart, const ttsweep_start *star
     for (int s = 0; s < nstart; s++) {
         ctx->stats.sweeps_total += sweeps[s];
         ctx->stats.sweeps_max = std::max(ctx->stats.sweeps_max, sweeps[s]);
+        // CELL kernel relaxes every cell in every pass; STRIP counts its active tiles
+        ctx->stats.cells_relaxed += ctx->kernel == TTSWEEP_KERNEL_STRIP
+            ? (long long)ctx->h_work[s] : (long long)sweeps[s] * ctx->stats.cells;
     }
     return anychange_ever ? 1 : 0;
 }

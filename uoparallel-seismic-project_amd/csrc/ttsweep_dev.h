@@ -55,6 +55,10 @@ struct StartDesc {
     // that have at least one dead edge: the STRIP kernel does not store into
     // them, the exact wave-per-cell kernel owns them.  Empty if lo > hi.
     int box_lo[3], box_hi[3];
+    // STRIP kernel activity tracking: tile_flags[parity][tile] != 0 iff some cell of
+    // that tile improved in the pass with that parity (see sweep_strip_kernel).
+    int *tile_flags;
+    unsigned long long *work;   // cells actually relaxed for this start (sum over passes)
 };
 
 // ---------------------------------------------------------------------------

@@ -29,13 +29,22 @@ hipError_t launch_sweep_cell(const DevLayout &L, const float *v, const StartDesc
 // Same contract as launch_sweep_cell, but cells inside a start's dead-edge box
 // (StartDesc::box_*) are left untouched; launch_sweep_special relaxes exactly
 // those cells with the full liveness rule.
+//
+// Activity tracking: a tile is relaxed in pass k only if a tile it reads from
+// (itself, its 8 in-plane neighbours, over all plane offsets) improved in pass
+// k-1; `parity` = k & 1 selects which half of StartDesc::tile_flags is written.
 size_t strip_lds_bytes(const StripPlan &plan);
+int strip_tiles(const DevLayout &L);            // tiles per start
 hipError_t launch_sweep_strip(const DevLayout &L, const float *v, const StartDesc *starts,
                               const int *active, int nactive, int *changed,
-                              const StripCol *cols, const StripPlan &plan, hipStream_t st);
+                              const StripCol *cols, const StripPlan &plan, int parity,
+                              hipStream_t st);
 hipError_t launch_sweep_special(const DevLayout &L, const float *v, const StartDesc *starts,
                                 const int *active, int nactive, int *changed,
                                 const CellEntry *entries, int nentries, int max_box_cells,
-                                hipStream_t st);
+                                int parity, hipStream_t st);
+// flags[1][*] = all_active ? 1 : (tile == start's tile); flags[0][*] = 0
+hipError_t launch_init_tile_flags(const DevLayout &L, const StartDesc &sd, bool all_active,
+                                  hipStream_t st);
 
 } // namespace ttsweep

@@ -203,7 +203,7 @@ __global__ void __launch_bounds__(STRIP_TB *STRIP_NS, 3)
 sweep_strip_kernel(DevLayout L, const float *__restrict__ v,
                    const StartDesc *__restrict__ starts, const int *__restrict__ active,
                    int *__restrict__ changed, const StripCol *__restrict__ cols,
-                   StripPlan plan, int btiles, int ctiles, unsigned nblocks)
+                   StripPlan plan, int btiles, int ctiles, unsigned nblocks, int parity)
 {
     static_assert(K == STRIP_K, "geometry constants assume K == STRIP_K");
     constexpr int W = K + 2 * STRIP_CF;
@@ -233,6 +233,26 @@ sweep_strip_kernel(DevLayout L, const float *__restrict__ v,
 
     const StartDesc sd = starts[s];
     float *__restrict__ T = sd.T;
+
+    // ---- activity test: did anything this tile reads from improve in the previous pass?
+    const int ntiles = L.n[0] * btiles * ctiles;
+    const int my_tile = (a * btiles + bt) * ctiles + ct;
+    int *__restrict__ cur_flags = sd.tile_flags + parity * ntiles;
+    {
+        const int *__restrict__ prev_flags = sd.tile_flags + (1 - parity) * ntiles;
+        int f = 0;
+        if (tid < 9 * (2 * plan.ra + 1)) {
+            const int da = tid / 9 - plan.ra;
+            const int r = tid % 9;
+            const int na = a + da, nb = bt + r / 3 - 1, nc = ct + r % 3 - 1;
+            if (na >= 0 && na < L.n[0] && nb >= 0 && nb < btiles && nc >= 0 && nc < ctiles)
+                f = prev_flags[(na * btiles + nb) * ctiles + nc];
+        }
+        if (!__syncthreads_or(f)) {
+            if (tid == 0) cur_flags[my_tile] = 0;
+            return;
+        }
+    }
 
     float *sv = smem;
     float *sT = smem + rows * STRIP_PW;
@@ -320,7 +340,40 @@ sweep_strip_kernel(DevLayout L, const float *__restrict__ v,
             improved = true;
         }
     }
-    if (__ballot(improved) != 0ull && lane == 0) atomicOr(&changed[s], 1);
+    const int any = __syncthreads_or(improved);
+    if (tid == 0) {
+        cur_flags[my_tile] = any;
+        if (any) atomicOr(&changed[s], 1);
+        const int wb = min(STRIP_TB, L.n[1] - b0), wc = min(STRIP_TC, L.n[2] - c0);
+        atomicAdd(sd.work, (unsigned long long)(wb * wc));
+    }
+}
+
+int strip_tiles(const DevLayout &L)
+{
+    return L.n[0] * ((L.n[1] + STRIP_TB - 1) / STRIP_TB) * ((L.n[2] + STRIP_TC - 1) / STRIP_TC);
+}
+
+__global__ void __launch_bounds__(256)
+init_tile_flags_kernel(int *__restrict__ flags, int ntiles, int start_tile)
+{
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= ntiles) return;
+    flags[t] = 0;
+    flags[ntiles + t] = (start_tile < 0 || t == start_tile) ? 1 : 0;
+}
+
+hipError_t launch_init_tile_flags(const DevLayout &L, const StartDesc &sd, bool all_active,
+                                  hipStream_t st)
+{
+    const int btiles = (L.n[1] + STRIP_TB - 1) / STRIP_TB;
+    const int ctiles = (L.n[2] + STRIP_TC - 1) / STRIP_TC;
+    const int ntiles = L.n[0] * btiles * ctiles;
+    const int start_tile = all_active ? -1
+        : (sd.sa * btiles + sd.sb / STRIP_TB) * ctiles + sd.sc / STRIP_TC;
+    hipLaunchKernelGGL(init_tile_flags_kernel, dim3((ntiles + 255) / 256), dim3(256), 0, st,
+                       sd.tile_flags, ntiles, start_tile);
+    return hipGetLastError();
 }
 
 size_t strip_lds_bytes(const StripPlan &plan)
@@ -330,7 +383,8 @@ size_t strip_lds_bytes(const StripPlan &plan)
 
 hipError_t launch_sweep_strip(const DevLayout &L, const float *v, const StartDesc *starts,
                               const int *active, int nactive, int *changed,
-                              const StripCol *cols, const StripPlan &plan, hipStream_t st)
+                              const StripCol *cols, const StripPlan &plan, int parity,
+                              hipStream_t st)
 {
     const int btiles = (L.n[1] + STRIP_TB - 1) / STRIP_TB;
     const int ctiles = (L.n[2] + STRIP_TC - 1) / STRIP_TC;
@@ -346,7 +400,7 @@ hipError_t launch_sweep_strip(const DevLayout &L, const float *v, const StartDes
     }
     hipLaunchKernelGGL(sweep_strip_kernel<STRIP_K>, dim3((unsigned)nblocks),
                        dim3(STRIP_TB, STRIP_NS), strip_lds_bytes(plan), st, L, v, starts, active,
-                       changed, cols, plan, btiles, ctiles, (unsigned)nblocks);
+                       changed, cols, plan, btiles, ctiles, (unsigned)nblocks, parity);
     return hipGetLastError();
 }
 
@@ -361,7 +415,7 @@ __global__ void __launch_bounds__(64)
 sweep_special_kernel(DevLayout L, const float *__restrict__ v,
                      const StartDesc *__restrict__ starts, const int *__restrict__ active,
                      int *__restrict__ changed, const CellEntry *__restrict__ entries,
-                     int nentries, int max_box_cells)
+                     int nentries, int max_box_cells, int parity)
 {
     const int s = active[blockIdx.x / max_box_cells];
     int cell = blockIdx.x % max_box_cells;
@@ -395,17 +449,22 @@ sweep_special_kernel(DevLayout L, const float *__restrict__ v,
     if (threadIdx.x == 0 && best < told) {
         T[ci] = best;
         atomicOr(&changed[s], 1);
+        // runs after the STRIP pass of the same parity has written its tile flags
+        const int btiles = (L.n[1] + STRIP_TB - 1) / STRIP_TB;
+        const int ctiles = (L.n[2] + STRIP_TC - 1) / STRIP_TC;
+        const int ntiles = L.n[0] * btiles * ctiles;
+        sd.tile_flags[parity * ntiles + (a * btiles + b / STRIP_TB) * ctiles + c / STRIP_TC] = 1;
     }
 }
 
 hipError_t launch_sweep_special(const DevLayout &L, const float *v, const StartDesc *starts,
                                 const int *active, int nactive, int *changed,
                                 const CellEntry *entries, int nentries, int max_box_cells,
-                                hipStream_t st)
+                                int parity, hipStream_t st)
 {
     if (nactive <= 0 || max_box_cells <= 0) return hipSuccess;
     hipLaunchKernelGGL(sweep_special_kernel, dim3((unsigned)(nactive * max_box_cells)), dim3(64), 0,
-                       st, L, v, starts, active, changed, entries, nentries, max_box_cells);
+                       st, L, v, starts, active, changed, entries, nentries, max_box_cells, parity);
     return hipGetLastError();
 }
 
