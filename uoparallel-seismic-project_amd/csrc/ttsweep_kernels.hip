@@ -198,6 +198,22 @@ hipError_t launch_sweep_cell(const DevLayout &L, const float *v, const StartDesc
 // +INF / 0) and no liveness tests.  The few cells that own a dead edge (inside
 // StartDesc::box) are computed but not stored; sweep_special_kernel owns them.
 
+// Workgroup-wide OR through the first words of the dynamic LDS region (no static
+// __shared__ object: it would shift the 16-byte alignment of the dynamic base).
+constexpr int STRIP_LDS_HEAD = 16;      // floats reserved in front of the slabs
+__device__ __forceinline__ bool block_or(bool pred, float *smem, int wave, int lane)
+{
+    int *words = reinterpret_cast<int *>(smem);
+    __syncthreads();                    // earlier readers of the words are done
+    const unsigned long long m = __ballot(pred);
+    if (lane == 0) words[wave] = (m != 0ull);
+    __syncthreads();
+    int any = 0;
+#pragma unroll
+    for (int w = 0; w < STRIP_NS; w++) any |= words[w];
+    return any != 0;
+}
+
 template <int K>
 __global__ void __launch_bounds__(STRIP_TB *STRIP_NS, 3)
 sweep_strip_kernel(DevLayout L, const float *__restrict__ v,
@@ -248,14 +264,14 @@ sweep_strip_kernel(DevLayout L, const float *__restrict__ v,
             if (na >= 0 && na < L.n[0] && nb >= 0 && nb < btiles && nc >= 0 && nc < ctiles)
                 f = prev_flags[(na * btiles + nb) * ctiles + nc];
         }
-        if (!__syncthreads_or(f)) {
+        if (!block_or(f != 0, smem, strip, lane)) {
             if (tid == 0) cur_flags[my_tile] = 0;
             return;
         }
     }
 
-    float *sv = smem;
-    float *sT = smem + rows * STRIP_PW;
+    float *sv = smem + STRIP_LDS_HEAD;
+    float *sT = sv + rows * STRIP_PW;
 
     // own cells: (a, b0 + lane, c0 + strip*K + q)
     const long long own = (long long)(a + L.lo[0]) * L.s0 + (long long)(b0 + lane + L.lo[1]) * L.s1
@@ -340,7 +356,7 @@ sweep_strip_kernel(DevLayout L, const float *__restrict__ v,
             improved = true;
         }
     }
-    const int any = __syncthreads_or(improved);
+    const int any = block_or(improved, smem, strip, lane);
     if (tid == 0) {
         cur_flags[my_tile] = any;
         if (any) atomicOr(&changed[s], 1);
@@ -378,7 +394,7 @@ hipError_t launch_init_tile_flags(const DevLayout &L, const StartDesc &sd, bool 
 
 size_t strip_lds_bytes(const StripPlan &plan)
 {
-    return (size_t)2 * (STRIP_TB + 2 * plan.rb) * STRIP_PW * sizeof(float);
+    return ((size_t)2 * (STRIP_TB + 2 * plan.rb) * STRIP_PW + STRIP_LDS_HEAD) * sizeof(float);
 }
 
 hipError_t launch_sweep_strip(const DevLayout &L, const float *v, const StartDesc *starts,
@@ -391,12 +407,13 @@ hipError_t launch_sweep_strip(const DevLayout &L, const float *v, const StartDes
     const long long nblocks = (long long)nactive * L.n[0] * btiles * ctiles;
     if (nblocks <= 0) return hipSuccess;
     if (nblocks > 0x7fffffffLL) return hipErrorInvalidValue;
-    static bool attr_set = false;
-    if (!attr_set) {
+    static size_t attr_bytes = 48 * 1024;      // default dynamic-LDS limit
+    if (strip_lds_bytes(plan) > attr_bytes) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(sweep_strip_kernel<STRIP_K>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                                           hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           (int)strip_lds_bytes(plan));
         if (e != hipSuccess) return e;
-        attr_set = true;
+        attr_bytes = strip_lds_bytes(plan);
     }
     hipLaunchKernelGGL(sweep_strip_kernel<STRIP_K>, dim3((unsigned)nblocks),
                        dim3(STRIP_TB, STRIP_NS), strip_lds_bytes(plan), st, L, v, starts, active,
