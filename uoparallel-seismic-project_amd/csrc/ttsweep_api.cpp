@@ -74,6 +74,10 @@ struct ttsweep_ctx {
     std::vector<std::array<int, 3>> special_offsets;   // device-axis offsets e: cell start - e owns a dead edge
     bool start_is_special = false;
     int max_box_cells = 0;                  // of the current solve
+    int2 *d_worklist = nullptr;             // STRIP: block -> (start, tile)
+    size_t worklist_cap = 0;
+    long long worklist_len = 0;
+    std::vector<std::vector<int>> tile_order;   // per start: tile ids, nearest to the start first
     int *d_tile_flags = nullptr;            // capacity_starts x 2 x tiles
     unsigned long long *d_work = nullptr;   // capacity_starts
     unsigned long long *h_work = nullptr;   // pinned
@@ -125,23 +129,33 @@ static void make_layout_cell(ttsweep_ctx *ctx)
     L.cells = L.s0 * L.p[0];
 }
 
-// Padded layout for the STRIP kernel.  The axis with the worst 64-cell tile
-// utilisation becomes the plane axis a (it is not tiled); the stride-1 axis c
-// gets the strips, b the lanes.
+// Padded layout for the STRIP kernel: picks which user axis becomes the plane axis
+// a, the lane axis b and the strip (stride-1) axis c.
 static void make_layout_strip(ttsweep_ctx *ctx)
 {
     DevLayout &L = ctx->L;
     const int n[3] = {ctx->nx, ctx->ny, ctx->nz};
-    auto util = [](int m) { return (double)m / (double)(((m + 63) / 64) * 64); };
-    int worst = 0;
-    for (int d = 1; d < 3; d++)
-        if (util(n[d]) < util(n[worst]) - 1e-12) worst = d;
+    // Lane axis b: an axis that fits into one wave (extent <= 64, the largest such)
+    // makes the activity units thin in that direction; otherwise the axis that
+    // fills 64-lane tiles best.  Strip axis c: of the two remaining axes the one
+    // that fills K-cell strips best.  The last axis is the plane axis a (untiled).
+    auto util = [](int m, int q) { return (double)m / (double)(((m + q - 1) / q) * q); };
+    int bax = -1;
+    for (int d = 0; d < 3; d++)
+        if (n[d] <= STRIP_TB && (bax < 0 || n[d] > n[bax])) bax = d;
+    if (bax < 0) {
+        bax = 0;
+        for (int d = 1; d < 3; d++)
+            if (util(n[d], STRIP_TB) > util(n[bax], STRIP_TB) + 1e-12) bax = d;
+    }
     int rest[2], k = 0;
     for (int d = 0; d < 3; d++)
-        if (d != worst) rest[k++] = d;
-    L.perm[0] = worst;
-    L.perm[1] = rest[0];
-    L.perm[2] = rest[1];
+        if (d != bax) rest[k++] = d;
+    int cax = rest[1], aax = rest[0];       // ties: keep the user's fastest axis as c
+    if (util(n[rest[0]], STRIP_K) > util(n[rest[1]], STRIP_K) + 1e-12) { cax = rest[0]; aax = rest[1]; }
+    L.perm[0] = aax;
+    L.perm[1] = bax;
+    L.perm[2] = cax;
     int r[3] = {0, 0, 0};
     for (const auto &e : ctx->pull) {
         const int u[3] = {e.di, e.dj, e.dk};
@@ -174,7 +188,6 @@ static int upload_strip_plan(ttsweep_ctx *ctx)
 {
     const DevLayout &L = ctx->L;
     StripPlan &plan = ctx->plan;
-    struct Key { int da, db; };
     std::vector<std::vector<StripCol>> per_plane(2 * plan.ra + 1);
     ctx->special_offsets.clear();
     ctx->start_is_special = false;
@@ -297,7 +310,7 @@ static int ensure_capacity(ttsweep_ctx *ctx, int nstart)
     HIPCHK(hipHostMalloc((void **)&ctx->h_active, nstart * sizeof(int)));
     HIPCHK(hipHostMalloc((void **)&ctx->h_changed, nstart * sizeof(int)));
     HIPCHK(hipMalloc((void **)&ctx->d_tile_flags,
-                     (size_t)nstart * 2 * std::max(strip_tiles(ctx->L), 1) * sizeof(int)));
+                     (size_t)nstart * 2 * std::max(strip_units(ctx->L), 1) * sizeof(int)));
     HIPCHK(hipMalloc((void **)&ctx->d_work, nstart * sizeof(unsigned long long)));
     HIPCHK(hipHostMalloc((void **)&ctx->h_work, nstart * sizeof(unsigned long long)));
     ctx->capacity_starts = nstart;
@@ -316,14 +329,83 @@ static int timed_event(ttsweep_ctx *ctx, hipEvent_t *out)
     return 0;
 }
 
+// STRIP work list.  The hardware deals consecutive blocks round-robin over the 8
+// XCDs (observed behaviour, used for speed only), so block b runs on XCD b % 8.
+// Every active start is given a set of XCDs (one XCD when there are >= 8 starts,
+// several when there are fewer) and its tiles are queued on those XCDs nearest to
+// the start point first.  Tiles of one start therefore mostly share one L2, and a
+// tile usually runs after the tiles between it and the start have finished their
+// update of this pass: fresh travel times then cross several tiles in ONE pass
+// instead of one tile per pass.  Correctness never depends on this order.
+static int build_worklist(ttsweep_ctx *ctx, int nactive)
+{
+    const int ntiles = strip_tiles(ctx->L);
+    constexpr int NX = 8;
+    std::vector<std::vector<int2>> per_xcd(NX);
+    if (nactive >= NX) {
+        // XCD x serves starts x, x+8, ...; interleave them rank by rank
+        for (int x = 0; x < NX; x++)
+            for (int k = 0; k < ntiles; k++)
+                for (int a = x; a < nactive; a += NX) {
+                    const int s = ctx->h_active[a];
+                    per_xcd[x].push_back(make_int2(s, ctx->tile_order[s][k]));
+                }
+    } else {
+        // start a owns XCDs a, a+nactive, ...; deal its tiles over them
+        for (int a = 0; a < nactive; a++) {
+            const int s = ctx->h_active[a];
+            std::vector<int> mine;
+            for (int x = a; x < NX; x += nactive) mine.push_back(x);
+            for (int k = 0; k < ntiles; k++)
+                per_xcd[mine[k % mine.size()]].push_back(make_int2(s, ctx->tile_order[s][k]));
+        }
+    }
+    size_t longest = 0;
+    for (const auto &q : per_xcd) longest = std::max(longest, q.size());
+    std::vector<int2> flat(longest * NX, make_int2(0, -1));
+    for (int x = 0; x < NX; x++)
+        for (size_t j = 0; j < per_xcd[x].size(); j++) flat[j * NX + x] = per_xcd[x][j];
+    if (flat.size() > ctx->worklist_cap) {
+        if (ctx->d_worklist) HIPCHK(hipFree(ctx->d_worklist));
+        ctx->d_worklist = nullptr;
+        HIPCHK(hipMalloc((void **)&ctx->d_worklist, flat.size() * sizeof(int2)));
+        ctx->worklist_cap = flat.size();
+    }
+    HIPCHK(hipMemcpyAsync(ctx->d_worklist, flat.data(), flat.size() * sizeof(int2),
+                          hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));      // `flat` is a stack-lifetime buffer
+    ctx->worklist_len = (long long)flat.size();
+    return 0;
+}
+
+// Tiles of one start ordered by distance (tile centre to start point).
+static void order_tiles(const ttsweep_ctx *ctx, const StartDesc &sd, std::vector<int> &order)
+{
+    const DevLayout &L = ctx->L;
+    const int btiles = (L.n[1] + STRIP_TB - 1) / STRIP_TB;
+    const int ctiles = (L.n[2] + STRIP_TC - 1) / STRIP_TC;
+    const int ntiles = L.n[0] * btiles * ctiles;
+    std::vector<std::pair<long long, int>> key(ntiles);
+    for (int t = 0; t < ntiles; t++) {
+        const int ct = t % ctiles, bt = (t / ctiles) % btiles, a = t / (ctiles * btiles);
+        const long long cb = std::min(bt * STRIP_TB + STRIP_TB / 2, L.n[1] - 1);
+        const long long cc = std::min(ct * STRIP_TC + STRIP_TC / 2, L.n[2] - 1);
+        const long long da = a - sd.sa, db = cb - sd.sb, dc = cc - sd.sc;
+        key[t] = {da * da + db * db + dc * dc, t};
+    }
+    std::sort(key.begin(), key.end());
+    order.resize(ntiles);
+    for (int t = 0; t < ntiles; t++) order[t] = key[t].second;
+}
+
 // One full-grid pass for the active starts.
 static int launch_pass(ttsweep_ctx *ctx, int nactive)
 {
     hipEvent_t e0, e1;
     if (ctx->timing && timed_event(ctx, &e0)) return -1;
     if (ctx->kernel == TTSWEEP_KERNEL_STRIP) {
-        HIPCHK(launch_sweep_strip(ctx->L, ctx->d_v, ctx->d_starts, ctx->d_active, nactive,
-                                  ctx->d_changed, ctx->d_strip_cols, ctx->plan,
+        HIPCHK(launch_sweep_strip(ctx->L, ctx->d_v, ctx->d_starts, ctx->d_worklist,
+                                  ctx->worklist_len, ctx->d_changed, ctx->d_strip_cols, ctx->plan,
                                   ctx->pass_index & 1, ctx->stream));
         HIPCHK(launch_sweep_special(ctx->L, ctx->d_v, ctx->d_starts, ctx->d_active, nactive,
                                     ctx->d_changed, ctx->d_cell_entries, ctx->n_cell_entries,
@@ -438,6 +520,7 @@ void ttsweep_destroy(ttsweep_ctx *ctx)
     (void)hipFree(ctx->d_active);
     (void)hipFree(ctx->d_changed);
     (void)hipFree(ctx->d_tile_flags);
+    (void)hipFree(ctx->d_worklist);
     (void)hipFree(ctx->d_work);
     if (ctx->h_work) (void)hipHostFree(ctx->h_work);
     if (ctx->h_starts) (void)hipHostFree(ctx->h_starts);
@@ -551,12 +634,15 @@ int ttsweep_solve_device(ttsweep_ctx *ctx, int nstart, const ttsweep_start *star
             for (int d = 0; d < 3; d++) vol *= std::max(sd.box_hi[d] - sd.box_lo[d] + 1, 0);
             ctx->max_box_cells = std::max<long long>(s == 0 ? 0 : ctx->max_box_cells, vol);
         }
-        sd.tile_flags = ctx->d_tile_flags + (size_t)s * 2 * std::max(strip_tiles(L), 1);
+        sd.tile_flags = ctx->d_tile_flags + (size_t)s * 2 * std::max(strip_units(L), 1);
         sd.work = ctx->d_work + s;
         if (init) HIPCHK(launch_init_tt(L, sd.T, sd.sidx, ctx->stream));
         else HIPCHK(launch_pack(L, tt_dev[s], sd.T, INFINITY, ctx->stream));
-        if (ctx->kernel == TTSWEEP_KERNEL_STRIP)
+        if (ctx->kernel == TTSWEEP_KERNEL_STRIP) {
             HIPCHK(launch_init_tile_flags(L, sd, /*all_active=*/!init, ctx->stream));
+            if ((int)ctx->tile_order.size() < nstart) ctx->tile_order.resize(nstart);
+            order_tiles(ctx, sd, ctx->tile_order[s]);
+        }
         ctx->h_active[s] = s;
     }
     HIPCHK(hipMemcpyAsync(ctx->d_starts, ctx->h_starts, nstart * sizeof(StartDesc),
@@ -565,9 +651,12 @@ int ttsweep_solve_device(ttsweep_ctx *ctx, int nstart, const ttsweep_start *star
                           hipMemcpyHostToDevice, ctx->stream));
     HIPCHK(hipMemsetAsync(ctx->d_work, 0, nstart * sizeof(unsigned long long), ctx->stream));
     ctx->pass_index = 0;
+    if (ctx->kernel == TTSWEEP_KERNEL_STRIP && build_worklist(ctx, nstart)) return -1;
 
     // driver loop: serial_new/...:151-170 without the break (:168-169)
     std::vector<int> sweeps(nstart, 0);
+    const bool trace = getenv("TTSWEEP_TRACE") != nullptr;
+    unsigned long long trace_prev = 0;
     int nactive = nstart;
     bool anychange_ever = false;
     while (nactive > 0) {
@@ -575,7 +664,17 @@ int ttsweep_solve_device(ttsweep_ctx *ctx, int nstart, const ttsweep_start *star
         if (launch_pass(ctx, nactive)) return -1;
         HIPCHK(hipMemcpyAsync(ctx->h_changed, ctx->d_changed, nstart * sizeof(int),
                               hipMemcpyDeviceToHost, ctx->stream));
+        if (trace)
+            HIPCHK(hipMemcpyAsync(ctx->h_work, ctx->d_work, nstart * sizeof(unsigned long long),
+                                  hipMemcpyDeviceToHost, ctx->stream));
         HIPCHK(hipStreamSynchronize(ctx->stream));
+        if (trace) {    // TTSWEEP_TRACE=1: per-pass activity on stderr
+            unsigned long long tot = 0;
+            for (int s = 0; s < nstart; s++) tot += ctx->h_work[s];
+            fprintf(stderr, "ttsweep pass %d: %d active starts, %.3f full-sweep equivalents relaxed\n",
+                    ctx->pass_index, nactive, (double)(tot - trace_prev) / (double)ctx->stats.cells);
+            trace_prev = tot;
+        }
         int keep = 0;
         for (int a = 0; a < nactive; a++) {
             const int s = ctx->h_active[a];
@@ -587,9 +686,11 @@ int ttsweep_solve_device(ttsweep_ctx *ctx, int nstart, const ttsweep_start *star
                 ctx->h_active[keep++] = s;
             }
         }
-        if (keep != nactive && keep > 0)
+        if (keep != nactive && keep > 0) {
             HIPCHK(hipMemcpyAsync(ctx->d_active, ctx->h_active, keep * sizeof(int),
                                   hipMemcpyHostToDevice, ctx->stream));
+            if (ctx->kernel == TTSWEEP_KERNEL_STRIP && build_worklist(ctx, keep)) return -1;
+        }
         nactive = keep;
     }
 

@@ -9,6 +9,9 @@
 // unchanged (fl(d*s)/2 == fl((d/2)*s) for normal floats).
 #include "ttsweep_kernels.h"
 
+#include <algorithm>
+#include <cstdlib>
+
 namespace ttsweep {
 
 // ===========================================================================
@@ -214,30 +217,60 @@ __device__ __forceinline__ bool block_or(bool pred, float *smem, int wave, int l
     return any != 0;
 }
 
-template <int K>
+
+// A column descriptor held in scalar registers.
+struct ColRegs {
+    int rowoff;
+    unsigned mask, chunks;
+    float h[16];
+};
+
+__device__ __forceinline__ ColRegs load_col(const StripCol *__restrict__ cols, int ci)
+{
+    ColRegs r;
+    const StripCol &c = cols[ci];
+    r.rowoff = c.rowoff;
+    r.mask = c.mask;
+    r.chunks = c.chunks;
+#pragma unroll
+    for (int t = 0; t < 16; t++) r.h[t] = c.h[t];
+    return r;
+}
+
+// Forces the whole descriptor to be resident in SGPRs here (one wait for all the
+// scalar loads instead of one load + wait in front of every offset).
+__device__ __forceinline__ void pin_col(ColRegs &r)
+{
+    asm volatile("; column descriptor resident"
+                 : "+s"(r.rowoff), "+s"(r.mask), "+s"(r.chunks), "+s"(r.h[1]), "+s"(r.h[2]),
+                   "+s"(r.h[3]), "+s"(r.h[4]), "+s"(r.h[5]), "+s"(r.h[6]), "+s"(r.h[7]),
+                   "+s"(r.h[8]), "+s"(r.h[9]), "+s"(r.h[10]), "+s"(r.h[11]), "+s"(r.h[12]),
+                   "+s"(r.h[13]), "+s"(r.h[14]), "+s"(r.h[15]));
+}
+
+template <int K, int VARIANT>
 __global__ void __launch_bounds__(STRIP_TB *STRIP_NS, 3)
 sweep_strip_kernel(DevLayout L, const float *__restrict__ v,
-                   const StartDesc *__restrict__ starts, const int *__restrict__ active,
+                   const StartDesc *__restrict__ starts, const int2 *__restrict__ work,
                    int *__restrict__ changed, const StripCol *__restrict__ cols,
-                   StripPlan plan, int btiles, int ctiles, unsigned nblocks, int parity)
+                   StripPlan plan, int btiles, int ctiles, int parity)
 {
     static_assert(K == STRIP_K, "geometry constants assume K == STRIP_K");
     constexpr int W = K + 2 * STRIP_CF;
     constexpr int NT = STRIP_TB * STRIP_NS;
     extern __shared__ __attribute__((aligned(16))) float smem[];
 
-    // XCD-aware block order: blocks b and b+8 share an XCD (and its L2); give each
-    // XCD a contiguous run of logical tiles, with the plane index fastest, so the
-    // 2*ra+1 planes a tile stages are mostly L2 hits left by its predecessor.
-    unsigned bid = blockIdx.x;
-    {
-        const unsigned per = nblocks / 8;
-        if (bid < per * 8) bid = (bid % 8) * per + bid / 8;
-    }
-    const int a = bid % L.n[0];   bid /= L.n[0];
-    const int ct = bid % ctiles;  bid /= ctiles;
-    const int bt = bid % btiles;  bid /= btiles;
-    const int s = active[bid];
+    // Block -> (start, tile) through a host-built work list (see build_worklist in
+    // ttsweep_api.cpp): entries are ordered so that consecutive blocks of one XCD
+    // (blocks b, b+8, b+16, ... share an XCD and its L2) walk the tiles of "their"
+    // starts from the start point outwards.
+    const int2 item = work[blockIdx.x];
+    const int s = item.x;
+    if (item.y < 0) return;                 // padding entry
+    int tile_id = item.y;
+    const int ct = tile_id % ctiles;  tile_id /= ctiles;
+    const int bt = tile_id % btiles;  tile_id /= btiles;
+    const int a = tile_id;
 
     const int lane = threadIdx.x;
     const int strip = threadIdx.y;
@@ -245,36 +278,45 @@ sweep_strip_kernel(DevLayout L, const float *__restrict__ v,
     const int b0 = bt * STRIP_TB;
     const int c0 = ct * STRIP_TC;
     const int rb = plan.rb;
-    const int rows = STRIP_TB + 2 * rb;
+    const int tb_eff = min(STRIP_TB, L.n[1]);       // lanes that can own a cell
+    const int rows = tb_eff + 2 * rb;
+    const int lane_r = min(lane, tb_eff - 1);       // idle lanes mirror a valid row
 
     const StartDesc sd = starts[s];
     float *__restrict__ T = sd.T;
 
-    // ---- activity test: did anything this tile reads from improve in the previous pass?
-    const int ntiles = L.n[0] * btiles * ctiles;
-    const int my_tile = (a * btiles + bt) * ctiles + ct;
-    int *__restrict__ cur_flags = sd.tile_flags + parity * ntiles;
+    // ---- activity test, per wave.  A "unit" is what one wave relaxes: plane a x (up to)
+    // 64 cells along b x one strip of K cells along c.  It has to be relaxed in this
+    // pass only if a unit it reads from (itself and its neighbours within the star's
+    // reach: +-ra planes, +-1 lane tile, +-1 strip) improved in the previous pass.
+    const int cstrips = ctiles * STRIP_NS;
+    const int nunits = L.n[0] * btiles * cstrips;
+    const int my_cs = ct * STRIP_NS + strip;
+    const int my_unit = (a * btiles + bt) * cstrips + my_cs;
+    int *__restrict__ cur_flags = sd.tile_flags + parity * nunits;
+    bool wave_active;
     {
-        const int *__restrict__ prev_flags = sd.tile_flags + (1 - parity) * ntiles;
+        const int *__restrict__ prev_flags = sd.tile_flags + (1 - parity) * nunits;
         int f = 0;
-        if (tid < 9 * (2 * plan.ra + 1)) {
-            const int da = tid / 9 - plan.ra;
-            const int r = tid % 9;
-            const int na = a + da, nb = bt + r / 3 - 1, nc = ct + r % 3 - 1;
-            if (na >= 0 && na < L.n[0] && nb >= 0 && nb < btiles && nc >= 0 && nc < ctiles)
-                f = prev_flags[(na * btiles + nb) * ctiles + nc];
+        for (int idx = lane; idx < 9 * (2 * plan.ra + 1); idx += 64) {
+            const int da = idx / 9 - plan.ra;
+            const int r = idx % 9;
+            const int na = a + da, nb = bt + r / 3 - 1, nc = my_cs + r % 3 - 1;
+            if (na >= 0 && na < L.n[0] && nb >= 0 && nb < btiles && nc >= 0 && nc < cstrips)
+                f |= prev_flags[(na * btiles + nb) * cstrips + nc];
         }
-        if (!block_or(f != 0, smem, strip, lane)) {
-            if (tid == 0) cur_flags[my_tile] = 0;
-            return;
-        }
+        wave_active = __ballot(f != 0) != 0ull;
+    }
+    if (!block_or(wave_active, smem, strip, lane)) {
+        if (lane == 0) cur_flags[my_unit] = 0;
+        return;
     }
 
     float *sv = smem + STRIP_LDS_HEAD;
     float *sT = sv + rows * STRIP_PW;
 
     // own cells: (a, b0 + lane, c0 + strip*K + q)
-    const long long own = (long long)(a + L.lo[0]) * L.s0 + (long long)(b0 + lane + L.lo[1]) * L.s1
+    const long long own = (long long)(a + L.lo[0]) * L.s0 + (long long)(b0 + lane_r + L.lo[1]) * L.s1
                         + (c0 + strip * K + L.lo[2]);
     float vc[K], acc[K];
 #pragma unroll
@@ -308,12 +350,17 @@ sweep_strip_kernel(DevLayout L, const float *__restrict__ v,
         }
         __syncthreads();
 
-        // ---- relax every column of this plane offset
+        // ---- relax every column of this plane offset.  The column descriptor lives
+        // in SGPRs; the NEXT column's descriptor is requested before this column's
+        // arithmetic so its scalar-load latency is hidden.
+        if (!wave_active) continue;         // this wave only helps staging
+        ColRegs cur = load_col(cols, cbeg);
         for (int ci = cbeg; ci < cend; ci++) {
-            const StripCol &col = cols[ci];
-            const int off = (lane + rb + col.rowoff) * STRIP_PW + strip * K;
-            const unsigned chunks = col.chunks;
-            const unsigned mask = col.mask;
+            pin_col(cur);
+            const ColRegs nxt = load_col(cols, min(ci + 1, cend - 1));
+            const int off = (lane_r + rb + cur.rowoff) * STRIP_PW + strip * K;
+            const unsigned chunks = cur.chunks;
+            const unsigned mask = cur.mask;
             float vN[W], tN[W];
 #pragma unroll
             for (int j = 0; j < W / 4; j++) {
@@ -327,7 +374,9 @@ sweep_strip_kernel(DevLayout L, const float *__restrict__ v,
 #pragma unroll
             for (int t = 1; t < 2 * STRIP_CF; t++) {
                 if (mask & (1u << t)) {
-                    const float h = col.h[t];
+                    float h = cur.h[t];
+                    if (VARIANT & 1)    // a VGPR copy: VALU ops with an SGPR operand issue at half rate
+                        asm volatile("v_mov_b32 %0, %1" : "=v"(h) : "s"(cur.h[t]));
 #pragma unroll
                     for (int q = 0; q < K; q++) {
                         const float sum = vc[q] + vN[q + t];
@@ -337,6 +386,7 @@ sweep_strip_kernel(DevLayout L, const float *__restrict__ v,
                     }
                 }
             }
+            cur = nxt;
         }
     }
 
@@ -344,24 +394,28 @@ sweep_strip_kernel(DevLayout L, const float *__restrict__ v,
     // dead-edge box of this start
     const int b = b0 + lane;
     const int cbase = c0 + strip * K;
-    const bool row_ok = b < L.n[1];
+    const bool row_ok = lane < tb_eff && b < L.n[1];
     const bool in_box_ab = a >= sd.box_lo[0] && a <= sd.box_hi[0] && b >= sd.box_lo[1] && b <= sd.box_hi[1];
     bool improved = false;
+    if (wave_active) {
 #pragma unroll
-    for (int q = 0; q < K; q++) {
-        const int c = cbase + q;
-        const bool special = in_box_ab && c >= sd.box_lo[2] && c <= sd.box_hi[2];
-        if (row_ok && c < L.n[2] && !special && acc[q] < T[own + q]) {
-            T[own + q] = acc[q];
-            improved = true;
+        for (int q = 0; q < K; q++) {
+            const int c = cbase + q;
+            const bool special = in_box_ab && c >= sd.box_lo[2] && c <= sd.box_hi[2];
+            if (row_ok && c < L.n[2] && !special && acc[q] < T[own + q]) {
+                T[own + q] = acc[q];
+                improved = true;
+            }
         }
     }
-    const int any = block_or(improved, smem, strip, lane);
-    if (tid == 0) {
-        cur_flags[my_tile] = any;
+    const bool any = __ballot(improved) != 0ull;
+    if (lane == 0) {
+        cur_flags[my_unit] = any;
         if (any) atomicOr(&changed[s], 1);
-        const int wb = min(STRIP_TB, L.n[1] - b0), wc = min(STRIP_TC, L.n[2] - c0);
-        atomicAdd(sd.work, (unsigned long long)(wb * wc));
+        if (wave_active) {
+            const int wb = min(tb_eff, L.n[1] - b0), wc = max(min(K, L.n[2] - cbase), 0);
+            atomicAdd(sd.work, (unsigned long long)(wb * wc));
+        }
     }
 }
 
@@ -370,13 +424,15 @@ int strip_tiles(const DevLayout &L)
     return L.n[0] * ((L.n[1] + STRIP_TB - 1) / STRIP_TB) * ((L.n[2] + STRIP_TC - 1) / STRIP_TC);
 }
 
+int strip_units(const DevLayout &L) { return strip_tiles(L) * STRIP_NS; }
+
 __global__ void __launch_bounds__(256)
-init_tile_flags_kernel(int *__restrict__ flags, int ntiles, int start_tile)
+init_tile_flags_kernel(int *__restrict__ flags, int nunits, int start_unit)
 {
     const int t = blockIdx.x * 256 + threadIdx.x;
-    if (t >= ntiles) return;
+    if (t >= nunits) return;
     flags[t] = 0;
-    flags[ntiles + t] = (start_tile < 0 || t == start_tile) ? 1 : 0;
+    flags[nunits + t] = (start_unit < 0 || t == start_unit) ? 1 : 0;
 }
 
 hipError_t launch_init_tile_flags(const DevLayout &L, const StartDesc &sd, bool all_active,
@@ -384,40 +440,41 @@ hipError_t launch_init_tile_flags(const DevLayout &L, const StartDesc &sd, bool 
 {
     const int btiles = (L.n[1] + STRIP_TB - 1) / STRIP_TB;
     const int ctiles = (L.n[2] + STRIP_TC - 1) / STRIP_TC;
-    const int ntiles = L.n[0] * btiles * ctiles;
-    const int start_tile = all_active ? -1
-        : (sd.sa * btiles + sd.sb / STRIP_TB) * ctiles + sd.sc / STRIP_TC;
-    hipLaunchKernelGGL(init_tile_flags_kernel, dim3((ntiles + 255) / 256), dim3(256), 0, st,
-                       sd.tile_flags, ntiles, start_tile);
+    const int cstrips = ctiles * STRIP_NS;
+    const int nunits = L.n[0] * btiles * cstrips;
+    const int start_unit = all_active ? -1
+        : (sd.sa * btiles + sd.sb / STRIP_TB) * cstrips + sd.sc / STRIP_K;
+    hipLaunchKernelGGL(init_tile_flags_kernel, dim3((nunits + 255) / 256), dim3(256), 0, st,
+                       sd.tile_flags, nunits, start_unit);
     return hipGetLastError();
 }
 
-size_t strip_lds_bytes(const StripPlan &plan)
+size_t strip_lds_bytes(const StripPlan &plan, int nb)
 {
-    return ((size_t)2 * (STRIP_TB + 2 * plan.rb) * STRIP_PW + STRIP_LDS_HEAD) * sizeof(float);
+    return ((size_t)2 * (std::min(STRIP_TB, nb) + 2 * plan.rb) * STRIP_PW + STRIP_LDS_HEAD)
+         * sizeof(float);
 }
 
 hipError_t launch_sweep_strip(const DevLayout &L, const float *v, const StartDesc *starts,
-                              const int *active, int nactive, int *changed,
+                              const int2 *work, long long nblocks, int *changed,
                               const StripCol *cols, const StripPlan &plan, int parity,
                               hipStream_t st)
 {
     const int btiles = (L.n[1] + STRIP_TB - 1) / STRIP_TB;
     const int ctiles = (L.n[2] + STRIP_TC - 1) / STRIP_TC;
-    const long long nblocks = (long long)nactive * L.n[0] * btiles * ctiles;
     if (nblocks <= 0) return hipSuccess;
     if (nblocks > 0x7fffffffLL) return hipErrorInvalidValue;
-    static size_t attr_bytes = 48 * 1024;      // default dynamic-LDS limit
-    if (strip_lds_bytes(plan) > attr_bytes) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(sweep_strip_kernel<STRIP_K>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize,
-                                           (int)strip_lds_bytes(plan));
+    static const int variant = getenv("TTSWEEP_VARIANT") ? atoi(getenv("TTSWEEP_VARIANT")) : 1;
+    auto kern = sweep_strip_kernel<STRIP_K, 1>;
+    if (variant == 0) kern = sweep_strip_kernel<STRIP_K, 0>;
+    const size_t lds = strip_lds_bytes(plan, L.n[1]);
+    if (lds > 48 * 1024) {      // above the default dynamic-LDS limit
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
-        attr_bytes = strip_lds_bytes(plan);
     }
-    hipLaunchKernelGGL(sweep_strip_kernel<STRIP_K>, dim3((unsigned)nblocks),
-                       dim3(STRIP_TB, STRIP_NS), strip_lds_bytes(plan), st, L, v, starts, active,
-                       changed, cols, plan, btiles, ctiles, (unsigned)nblocks, parity);
+    hipLaunchKernelGGL(kern, dim3((unsigned)nblocks), dim3(STRIP_TB, STRIP_NS), lds, st, L, v,
+                       starts, work, changed, cols, plan, btiles, ctiles, parity);
     return hipGetLastError();
 }
 
@@ -468,9 +525,9 @@ sweep_special_kernel(DevLayout L, const float *__restrict__ v,
         atomicOr(&changed[s], 1);
         // runs after the STRIP pass of the same parity has written its tile flags
         const int btiles = (L.n[1] + STRIP_TB - 1) / STRIP_TB;
-        const int ctiles = (L.n[2] + STRIP_TC - 1) / STRIP_TC;
-        const int ntiles = L.n[0] * btiles * ctiles;
-        sd.tile_flags[parity * ntiles + (a * btiles + b / STRIP_TB) * ctiles + c / STRIP_TC] = 1;
+        const int cstrips = ((L.n[2] + STRIP_TC - 1) / STRIP_TC) * STRIP_NS;
+        const int nunits = L.n[0] * btiles * cstrips;
+        sd.tile_flags[parity * nunits + (a * btiles + b / STRIP_TB) * cstrips + c / STRIP_K] = 1;
     }
 }
 
