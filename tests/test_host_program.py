@@ -1,0 +1,68 @@
+"""GPU tier: the plain-C host program (uoparallel-seismic-project_amd/host/
+sweep-tt-multistart.c), i.e. the reference's main() with sweepXYZ forwarding to the
+C ABI, run end to end on real files: .vbox in, star + start text files in,
+output.tt out (format of serial_new/sweep-tt-multistart.c:176-194)."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+
+pytestmark = pytest.mark.gpu
+
+HOST_DIR = os.path.join(ROOT, "uoparallel-seismic-project_amd", "host")
+EXE = os.path.join(HOST_DIR, "sweep-tt-multistart")
+
+
+@pytest.fixture(scope="module")
+def exe(pkg):
+    r = subprocess.run(["make", "-C", HOST_DIR], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    return EXE
+
+
+def test_host_program_end_to_end(exe, pkg, oracle, tmp_path):
+    shape = (30, 26, 14)
+    v = pkg.inputs.velocity_model(*shape, seed=8)
+    pkg.inputs.write_vbox(str(tmp_path / "model.vbox"), v)
+    starts = np.array([[15, 13, 13], [0, 0, 0], [29, 3, 7]], dtype=np.int32)
+    (tmp_path / "starts.txt").write_text(
+        f"{len(starts)}\n" + "".join(f"{i} {j} {k}\n" for i, j, k in starts))
+    star = pkg.inputs.star_path("818")
+    r = subprocess.run([exe, "model.vbox", star, "starts.txt"], cwd=tmp_path,
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    out = r.stdout
+    # the reference's progress lines (serial_new/...:80-166)
+    assert "Velocity model dimensions: 30 x 26 x 14" in out
+    assert "Forward star size: 818" in out
+    assert "Delta: 10.000000" in out
+    assert "starting point 2: 29 3 7" in out
+    assert "sweep 1 begin" in out and "sweep 2 finished: anychange = 0" in out
+    assert "sweep 3 begin" not in out
+
+    lines = (tmp_path / "output.tt").read_text().splitlines()
+    assert lines[0] == "30 26 14"
+    n = v.size
+    assert len(lines) == 1 + len(starts) * (1 + n)
+    fs = oracle.make_star(oracle.read_triples(star))
+    for s, st in enumerate(starts):
+        base = 1 + s * (1 + n)
+        assert lines[base] == f"starting point: {s}"
+        want, _, _ = oracle.converge(v, fs, st, order=1)
+        # spot-check the text of a few cells and parse all values
+        first = lines[base + 1]
+        assert first == "travel time for (0,0,0): %f 0 0 0" % want[0, 0, 0]
+        got = np.array([float(l.split(": ")[1].split()[0]) for l in lines[base + 1: base + 1 + n]])
+        exp = np.array([float("%f" % x) for x in want.reshape(-1)])
+        assert np.array_equal(got, exp), s
+
+
+def test_host_program_rejects_bad_input(exe, tmp_path):
+    r = subprocess.run([exe], cwd=tmp_path, capture_output=True, text=True)
+    assert r.returncode == 1 and "usage" in r.stdout
+    (tmp_path / "junk.vbox").write_bytes(b"not a vbox file at all")
+    r = subprocess.run([exe, "junk.vbox", "x", "y"], cwd=tmp_path, capture_output=True, text=True)
+    assert r.returncode == 1 and "Cannot open velocity model file" in r.stdout
