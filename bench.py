@@ -40,7 +40,7 @@ BYTES_PER_CELL_SWEEP = 12           # read v, read tt, write tt
 LANEOPS_PER_RELAX = 4               # add, mul, add, min
 
 
-def cpu_baseline(P, v, offs, start, sweeps=2):
+def cpu_baseline(P, v, offs, start, sweeps=4):
     """The CPU restatement of serial_new (oracle/, kind "port") timed on this
     host: `sweeps` reference-order passes of one start from the initial state."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
