@@ -66,8 +66,12 @@ def main():
     ap.add_argument("--grid", default="241,241,51")
     ap.add_argument("--star", default="818")
     ap.add_argument("--starts", default="24")
+    ap.add_argument("--nstarts", type=int, default=0, help="use only the first N start points")
     ap.add_argument("--kernel", type=int, default=0)
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
+    ap.add_argument("--backend", default="nccl",
+                    help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only to rehearse "
+                         "the multi-rank path on a box with fewer GPUs than ranks)")
     args = ap.parse_args()
 
     import torch
@@ -78,19 +82,25 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     dist = None
+    ndev = torch.cuda.device_count()
+    dev_index = local_rank % max(ndev, 1)
+    dev = torch.device("cuda", dev_index)
+    torch.cuda.set_device(dev)
     if world > 1:
         import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(args.backend)
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
-    dev = torch.device("cuda", local_rank)
-    torch.cuda.set_device(dev)
 
     nx, ny, nz = map(int, args.grid.split(","))
     cells = nx * ny * nz
     offs = P.inputs.read_triples(P.inputs.star_path(args.star))
     fs = P.inputs.make_fs(offs)
     starts = P.inputs.read_triples(P.inputs.starts_path(args.starts))
+    if args.nstarts:
+        starts = starts[:args.nstarts]
     if (nx, ny, nz) != (241, 241, 51):
         starts = P.inputs.scaled_starts(starts, nx, ny, nz)
         v_dev = P.inputs.velocity_model_device(nx, ny, nz, 20160507, dev)
@@ -102,7 +112,7 @@ def main():
     mine = P.multistart.shard_starts(nstart, world, rank)
     my_starts = starts[mine]
 
-    sol = P.TravelTimeSolver((nx, ny, nz), fs, device=local_rank)
+    sol = P.TravelTimeSolver((nx, ny, nz), fs, device=dev_index)
     if args.kernel:
         sol.set_option(P.OPT_KERNEL, args.kernel)
     sol.set_velocity(v_dev)
@@ -110,6 +120,8 @@ def main():
 
     def step():
         sol.solve_device(my_starts, tt, init=True)
+        if dist is not None and args.backend != "nccl":     # rehearsal: gather through the host
+            return P.multistart.gather_boxes(tt.cpu(), nstart, dist, dst=0)
         return P.multistart.gather_boxes(tt, nstart, dist, dst=0)
 
     def fence():
@@ -132,7 +144,8 @@ def main():
     dt = time.perf_counter() - t0
 
     # max over ranks of the elapsed time, sum over ranks of the passes executed
-    agg = torch.tensor([dt, float(sweeps_local), float(relaxed_local)], dtype=torch.float64, device=dev)
+    agg = torch.tensor([dt, float(sweeps_local), float(relaxed_local)], dtype=torch.float64,
+                       device=dev if args.backend == "nccl" else "cpu")
     if dist is not None:
         tmax = agg[:1].clone()
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)

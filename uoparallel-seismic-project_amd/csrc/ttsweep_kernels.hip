@@ -377,12 +377,21 @@ sweep_strip_kernel(DevLayout L, const float *__restrict__ v,
                     float h = cur.h[t];
                     if (VARIANT & 1)    // a VGPR copy: VALU ops with an SGPR operand issue at half rate
                         asm volatile("v_mov_b32 %0, %1" : "=v"(h) : "s"(cur.h[t]));
+                    // G independent relaxations are kept in flight: written as one
+                    // add/mul/add/min chain per cell the compiler serialises them on a
+                    // single temporary and every VALU op waits for its predecessor
+                    constexpr int G = 8;
 #pragma unroll
-                    for (int q = 0; q < K; q++) {
-                        const float sum = vc[q] + vN[q + t];
-                        const float delay = h * sum;
-                        const float cand = delay + tN[q + t];
-                        acc[q] = fminf(acc[q], cand);
+                    for (int q0 = 0; q0 < K; q0 += G) {
+                        float x[G];
+#pragma unroll
+                        for (int i = 0; i < G; i++) x[i] = vc[q0 + i] + vN[q0 + i + t];
+#pragma unroll
+                        for (int i = 0; i < G; i++) x[i] = h * x[i];
+#pragma unroll
+                        for (int i = 0; i < G; i++) x[i] = x[i] + tN[q0 + i + t];
+#pragma unroll
+                        for (int i = 0; i < G; i++) acc[q0 + i] = fminf(acc[q0 + i], x[i]);
                     }
                 }
             }
