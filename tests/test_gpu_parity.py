@@ -202,3 +202,77 @@ def test_full_size_fixed_point_properties(P, oracle, full):
     open_edges, ninf = oracle.validate(full, tts[0], oracle.make_star(
         oracle.read_triples(P.inputs.star_path("818"))), starts[0])
     assert (open_edges, ninf) == (0, 0)
+
+
+# ---------------------------------------------------------------------------
+# BASELINE.json config 4: synthetic 512 x 512 x 256 (no CPU oracle run is feasible:
+# one reference sweep is ~5 min).  Size-independent properties instead.
+# ---------------------------------------------------------------------------
+
+def sampled_open_edges(v, tt, offs, start, nsample, seed):
+    """The reference's own store conditions (serial_new/...:219-249) evaluated with
+    numpy float32 arithmetic at `nsample` random centre cells x all star entries
+    l < starsize-1.  Returns the number of (cell, offset) pairs a reference sweep
+    would still store through (0 at the fixed point)."""
+    rng = np.random.default_rng(seed)
+    shape = np.array(v.shape)
+    L = len(offs) - 1
+    d = (np.float32(10.0) * np.sqrt((offs[:L].astype(np.int64) ** 2).sum(1).astype(np.float64))
+         .astype(np.float32)).astype(np.float32)
+    c = np.stack([rng.integers(0, n, size=nsample) for n in shape], axis=1)
+    c = c[~np.all(c == np.asarray(start), axis=1)]                  # centre == start is skipped
+    # make sure the neighbourhood of the start and the grid corners are covered
+    open_edges = 0
+    for lo in range(0, len(c), 2048):
+        cc = c[lo:lo + 2048]
+        o = cc[:, None, :] + offs[None, :L, :]
+        ok = np.all((o >= 0) & (o < shape), axis=2)
+        oc = np.clip(o, 0, shape - 1)
+        vc = v[cc[:, 0], cc[:, 1], cc[:, 2]][:, None]
+        vo = v[oc[..., 0], oc[..., 1], oc[..., 2]]
+        tc = tt[cc[:, 0], cc[:, 1], cc[:, 2]][:, None]
+        to = tt[oc[..., 0], oc[..., 1], oc[..., 2]]
+        delay = ((d[None, :] * (vc + vo).astype(np.float32)).astype(np.float32)
+                 * np.float32(0.5)).astype(np.float32)
+        bad = ((delay + to).astype(np.float32) < tc) | ((delay + tc).astype(np.float32) < to)
+        open_edges += int((bad & ok).sum())
+    return open_edges
+
+
+def test_sampled_checker_detects_unconverged_state(P, golden24, oracle):
+    """The sampled validator itself: 0 on a converged fixture, > 0 one pass earlier."""
+    offs = golden24.star("818")
+    m = golden24.meta["pass_818"]
+    start = np.array(m["start"])
+    conv, _, _ = oracle.converge(golden24.v, oracle.make_star(offs), start)
+    assert sampled_open_edges(golden24.v, conv, offs, start, 4000, 1) == 0
+    assert sampled_open_edges(golden24.v, golden24.z["pass1_818"], offs, start, 4000, 1) > 0
+
+
+def test_512_grid_properties(P):
+    """818-FS on 512x512x256: the STRIP and CELL kernels (independent implementations,
+    different layouts and schedules) agree bit for bit, no INFINITY is left, the start
+    stays 0, a second solve changes nothing, and the reference's store conditions
+    hold at 20000 sampled cells."""
+    import torch
+    shape = (512, 512, 256)
+    dev = torch.device("cuda:0")
+    v_dev = P.inputs.velocity_model_device(*shape, 20160507, dev)
+    offs = P.inputs.read_triples(P.inputs.star_path("818"))
+    fs = P.inputs.make_fs(offs)
+    starts = P.inputs.scaled_starts(P.inputs.read_triples(P.inputs.starts_path("111")), *shape)[:1]
+    out = {}
+    for kernel in (2, 1):
+        with P.TravelTimeSolver(shape, fs) as sol:
+            sol.set_option(P.OPT_KERNEL, kernel)
+            sol.set_velocity(v_dev)
+            tt = torch.empty((1,) + shape, dtype=torch.float32, device=dev)
+            assert sol.solve_device(starts, tt, init=True) == 1
+            if kernel == 2:
+                assert sol.solve_device(starts, tt, init=False) == 0
+            out[kernel] = tt[0].cpu().numpy()
+    assert np.array_equal(out[1].view(np.uint32), out[2].view(np.uint32))
+    tt = out[2]
+    assert np.isfinite(tt).all() and tt[tuple(starts[0])] == 0 and (tt >= 0).all()
+    v = v_dev.cpu().numpy()
+    assert sampled_open_edges(v, tt, offs, starts[0], 20000, 2) == 0
