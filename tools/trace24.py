@@ -1,0 +1,11 @@
+import sys, numpy as np, torch
+sys.path.insert(0,'/root/repo')
+import ttsweep_pkg; P=ttsweep_pkg.load()
+v=P.inputs.velocity_model(241,241,51,20160507)
+fs=P.inputs.make_fs(P.inputs.read_triples(P.inputs.star_path('818')))
+starts=P.inputs.read_triples(P.inputs.starts_path('24'))
+dev=torch.device('cuda:0')
+with P.TravelTimeSolver(v.shape,fs) as sol:
+    sol.set_velocity(torch.from_numpy(v).to(dev))
+    tt=torch.empty((len(starts),)+v.shape,dtype=torch.float32,device=dev)
+    sol.solve_device(starts,tt,init=True); print(sol.stats())

@@ -9,6 +9,7 @@
 
 #include <algorithm>
 #include <array>
+#include <chrono>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -311,8 +312,8 @@ static int ensure_capacity(ttsweep_ctx *ctx, int nstart)
     HIPCHK(hipHostMalloc((void **)&ctx->h_changed, nstart * sizeof(int)));
     HIPCHK(hipMalloc((void **)&ctx->d_tile_flags,
                      (size_t)nstart * 2 * std::max(strip_units(ctx->L), 1) * sizeof(int)));
-    HIPCHK(hipMalloc((void **)&ctx->d_work, nstart * sizeof(unsigned long long)));
-    HIPCHK(hipHostMalloc((void **)&ctx->h_work, nstart * sizeof(unsigned long long)));
+    HIPCHK(hipMalloc((void **)&ctx->d_work, 2 * nstart * sizeof(unsigned long long)));
+    HIPCHK(hipHostMalloc((void **)&ctx->h_work, 2 * nstart * sizeof(unsigned long long)));
     ctx->capacity_starts = nstart;
     return 0;
 }
@@ -391,7 +392,14 @@ static void order_tiles(const ttsweep_ctx *ctx, const StartDesc &sd, std::vector
         const long long cb = std::min(bt * STRIP_TB + STRIP_TB / 2, L.n[1] - 1);
         const long long cc = std::min(ct * STRIP_TC + STRIP_TC / 2, L.n[2] - 1);
         const long long da = a - sd.sa, db = cb - sd.sb, dc = cc - sd.sc;
-        key[t] = {da * da + db * db + dc * dc, t};
+        static const int order_mode = getenv("TTSWEEP_ORDER") ? atoi(getenv("TTSWEEP_ORDER")) : 8;
+        if (order_mode == 0) key[t] = {((long long)bt * ctiles + ct) * L.n[0] + a, t};   // plane fastest
+        else if (order_mode == 1) key[t] = {da * da + db * db + dc * dc, t};
+        else {      // runs of `order_mode` consecutive planes, runs ordered by distance
+            const long long ca = (a / order_mode) * order_mode + order_mode / 2;
+            const long long dq = ca - sd.sa;
+            key[t] = {(dq * dq + db * db + dc * dc) * 64 + a % order_mode, t};
+        }
     }
     std::sort(key.begin(), key.end());
     order.resize(ntiles);
@@ -635,7 +643,7 @@ int ttsweep_solve_device(ttsweep_ctx *ctx, int nstart, const ttsweep_start *star
             ctx->max_box_cells = std::max<long long>(s == 0 ? 0 : ctx->max_box_cells, vol);
         }
         sd.tile_flags = ctx->d_tile_flags + (size_t)s * 2 * std::max(strip_units(L), 1);
-        sd.work = ctx->d_work + s;
+        sd.work = ctx->d_work + 2 * s;
         if (init) HIPCHK(launch_init_tt(L, sd.T, sd.sidx, ctx->stream));
         else HIPCHK(launch_pack(L, tt_dev[s], sd.T, INFINITY, ctx->stream));
         if (ctx->kernel == TTSWEEP_KERNEL_STRIP) {
@@ -649,31 +657,36 @@ int ttsweep_solve_device(ttsweep_ctx *ctx, int nstart, const ttsweep_start *star
                           hipMemcpyHostToDevice, ctx->stream));
     HIPCHK(hipMemcpyAsync(ctx->d_active, ctx->h_active, nstart * sizeof(int),
                           hipMemcpyHostToDevice, ctx->stream));
-    HIPCHK(hipMemsetAsync(ctx->d_work, 0, nstart * sizeof(unsigned long long), ctx->stream));
+    HIPCHK(hipMemsetAsync(ctx->d_work, 0, 2 * nstart * sizeof(unsigned long long), ctx->stream));
     ctx->pass_index = 0;
     if (ctx->kernel == TTSWEEP_KERNEL_STRIP && build_worklist(ctx, nstart)) return -1;
 
     // driver loop: serial_new/...:151-170 without the break (:168-169)
     std::vector<int> sweeps(nstart, 0);
     const bool trace = getenv("TTSWEEP_TRACE") != nullptr;
-    unsigned long long trace_prev = 0;
+    unsigned long long trace_prev = 0, trace_prev_wg = 0;
     int nactive = nstart;
     bool anychange_ever = false;
     while (nactive > 0) {
+        const auto t_pass = std::chrono::steady_clock::now();
         HIPCHK(hipMemsetAsync(ctx->d_changed, 0, nstart * sizeof(int), ctx->stream));
         if (launch_pass(ctx, nactive)) return -1;
         HIPCHK(hipMemcpyAsync(ctx->h_changed, ctx->d_changed, nstart * sizeof(int),
                               hipMemcpyDeviceToHost, ctx->stream));
         if (trace)
-            HIPCHK(hipMemcpyAsync(ctx->h_work, ctx->d_work, nstart * sizeof(unsigned long long),
+            HIPCHK(hipMemcpyAsync(ctx->h_work, ctx->d_work, 2 * nstart * sizeof(unsigned long long),
                                   hipMemcpyDeviceToHost, ctx->stream));
         HIPCHK(hipStreamSynchronize(ctx->stream));
         if (trace) {    // TTSWEEP_TRACE=1: per-pass activity on stderr
-            unsigned long long tot = 0;
-            for (int s = 0; s < nstart; s++) tot += ctx->h_work[s];
-            fprintf(stderr, "ttsweep pass %d: %d active starts, %.3f full-sweep equivalents relaxed\n",
-                    ctx->pass_index, nactive, (double)(tot - trace_prev) / (double)ctx->stats.cells);
+            unsigned long long tot = 0, wgs = 0;
+            for (int s = 0; s < nstart; s++) { tot += ctx->h_work[2 * s]; wgs += ctx->h_work[2 * s + 1]; }
+            const double us = std::chrono::duration<double, std::micro>(
+                                  std::chrono::steady_clock::now() - t_pass).count();
+            fprintf(stderr, "ttsweep pass %d: %d active starts, %.3f full-sweep equivalents relaxed, "
+                    "%llu workgroups ran, %.0f us\n", ctx->pass_index, nactive,
+                    (double)(tot - trace_prev) / (double)ctx->stats.cells, wgs - trace_prev_wg, us);
             trace_prev = tot;
+            trace_prev_wg = wgs;
         }
         int keep = 0;
         for (int a = 0; a < nactive; a++) {
@@ -696,7 +709,7 @@ int ttsweep_solve_device(ttsweep_ctx *ctx, int nstart, const ttsweep_start *star
 
     for (int s = 0; s < nstart; s++)
         HIPCHK(launch_unpack(L, ctx->h_starts[s].T, tt_dev[s], ctx->stream));
-    HIPCHK(hipMemcpyAsync(ctx->h_work, ctx->d_work, nstart * sizeof(unsigned long long),
+    HIPCHK(hipMemcpyAsync(ctx->h_work, ctx->d_work, 2 * nstart * sizeof(unsigned long long),
                           hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipEventRecord(ctx->ev_solve1, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
@@ -713,7 +726,7 @@ int ttsweep_solve_device(ttsweep_ctx *ctx, int nstart, const ttsweep_start *star
         ctx->stats.sweeps_max = std::max(ctx->stats.sweeps_max, sweeps[s]);
         // CELL kernel relaxes every cell in every pass; STRIP counts its active tiles
         ctx->stats.cells_relaxed += ctx->kernel == TTSWEEP_KERNEL_STRIP
-            ? (long long)ctx->h_work[s] : (long long)sweeps[s] * ctx->stats.cells;
+            ? (long long)ctx->h_work[2 * s] : (long long)sweeps[s] * ctx->stats.cells;
     }
     return anychange_ever ? 1 : 0;
 }

@@ -312,6 +312,8 @@ sweep_strip_kernel(DevLayout L, const float *__restrict__ v,
         return;
     }
 
+    if (tid == 0) atomicAdd(sd.work + 1, 1ull);     // workgroups that had to run (statistics)
+
     float *sv = smem + STRIP_LDS_HEAD;
     float *sT = sv + rows * STRIP_PW;
 
