@@ -7,6 +7,18 @@
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 constexpr int K = 16, CF = 8, W = K + 2 * CF;
 
+
+// 4 independent packed chains, stage-major, so that no instruction depends on one of the
+// previous three (the compiler serialises the chains on one temporary pair + s_nop).
+#define PK4(x0, x1, x2, x3, a0, a1, a2, a3, b0, b1, b2, b3, c0, c1, c2, c3, h2)                     \
+    asm volatile("v_pk_add_f32 %0, %4, %8\n\tv_pk_add_f32 %1, %5, %9\n\tv_pk_add_f32 %2, %6, %10\n\t"   \
+                 "v_pk_add_f32 %3, %7, %11\n\tv_pk_mul_f32 %0, %0, %16\n\tv_pk_mul_f32 %1, %1, %16\n\t"  \
+                 "v_pk_mul_f32 %2, %2, %16\n\tv_pk_mul_f32 %3, %3, %16\n\tv_pk_add_f32 %0, %0, %12\n\t"  \
+                 "v_pk_add_f32 %1, %1, %13\n\tv_pk_add_f32 %2, %2, %14\n\tv_pk_add_f32 %3, %3, %15"        \
+                 : "=&v"(x0), "=&v"(x1), "=&v"(x2), "=&v"(x3)                                          \
+                 : "v"(a0), "v"(a1), "v"(a2), "v"(a3), "v"(b0), "v"(b1), "v"(b2), "v"(b3), "v"(c0),    \
+                   "v"(c1), "v"(c2), "v"(c3), "v"(h2))
+
 template <int MODE>
 __device__ __forceinline__ void relax_column(unsigned mask, const float *hs_arr, unsigned desc,
                                              const f32x2 (&vc2e)[K / 2], const f32x2 (&vc2o)[K / 2 - 1],
@@ -19,7 +31,16 @@ __device__ __forceinline__ void relax_column(unsigned mask, const float *hs_arr,
             if (MODE == 0) { const float hs = __int_as_float(__builtin_amdgcn_readlane((int)desc, 4 + t)); asm volatile("v_mov_b32 %0, %1" : "=v"(hv) : "s"(hs)); }
             else hv = hs_arr[t];
             const f32x2 h2 = {hv, hv};
-            if ((t & 1) == 0) {
+            if ((t & 1) == 0 && MODE == 2) {
+                f32x2 x[K / 2];
+                PK4(x[0], x[1], x[2], x[3], vc2e[0], vc2e[1], vc2e[2], vc2e[3], vN2[t / 2], vN2[1 + t / 2], vN2[2 + t / 2], vN2[3 + t / 2], tN2[t / 2], tN2[1 + t / 2], tN2[2 + t / 2], tN2[3 + t / 2], h2);
+                PK4(x[4], x[5], x[6], x[7], vc2e[4], vc2e[5], vc2e[6], vc2e[7], vN2[4 + t / 2], vN2[5 + t / 2], vN2[6 + t / 2], vN2[7 + t / 2], tN2[4 + t / 2], tN2[5 + t / 2], tN2[6 + t / 2], tN2[7 + t / 2], h2);
+#pragma unroll
+                for (int p = 0; p < K / 2; p++) {
+                    acc[2 * p] = fminf(acc[2 * p], x[p].x);
+                    acc[2 * p + 1] = fminf(acc[2 * p + 1], x[p].y);
+                }
+            } else if ((t & 1) == 0) {
                 f32x2 x[K / 2];
 #pragma unroll
                 for (int p = 0; p < K / 2; p++) x[p] = vc2e[p] + vN2[p + t / 2];
@@ -96,9 +117,9 @@ int main()
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     if (getenv("MASK")) { unsigned m = strtoul(getenv("MASK"), 0, 16); nrel = 0; for (int c = 0; c < ncols; c++) { cols[c * 20 + 1] = m; nrel += __builtin_popcount(m); } hipMemcpy(dc, cols.data(), cols.size() * 4, hipMemcpyHostToDevice); }
     printf("columns %d, offsets %ld\n", ncols, nrel);
-    for (int mode = 0; mode < 2; mode++) for (int wps : {1, 2}) {
+    for (int mode = 1; mode < 3; mode++) for (int wps : {1, 2}) {
         int blocks = 256 * wps, iters = 20;
-        auto k = mode ? kern<1> : kern<0>;
+        auto k = mode == 2 ? kern<2> : kern<1>;
         k<<<blocks, 256>>>(out, dc, ncols, 2); hipDeviceSynchronize();
         hipEventRecord(e0); k<<<blocks, 256>>>(out, dc, ncols, iters); hipEventRecord(e1); hipDeviceSynchronize();
         float ms; hipEventElapsedTime(&ms, e0, e1);

@@ -216,6 +216,8 @@ static int upload_strip_plan(ttsweep_ctx *ctx)
     for (int ia = 0; ia <= 2 * plan.ra; ia++) {
         plan.first[ia] = (int)flat.size();
         flat.insert(flat.end(), per_plane[ia].begin(), per_plane[ia].end());
+        plan.nent[ia] = 0;
+        for (const auto &c : per_plane[ia]) plan.nent[ia] += __builtin_popcount(c.mask);
     }
     plan.first[2 * plan.ra + 1] = (int)flat.size();
     if (ctx->d_strip_cols) HIPCHK(hipFree(ctx->d_strip_cols));
@@ -684,7 +686,9 @@ int ttsweep_solve_device(ttsweep_ctx *ctx, int nstart, const ttsweep_start *star
                                   std::chrono::steady_clock::now() - t_pass).count();
             fprintf(stderr, "ttsweep pass %d: %d active starts, %.3f full-sweep equivalents relaxed, "
                     "%llu workgroups ran, %.0f us\n", ctx->pass_index, nactive,
-                    (double)(tot - trace_prev) / (double)ctx->stats.cells, wgs - trace_prev_wg, us);
+                    (double)(tot - trace_prev) / (double)ctx->stats.cells
+                        / (double)std::max<size_t>(ctx->pull.size(), 1),
+                    wgs - trace_prev_wg, us);
             trace_prev = tot;
             trace_prev_wg = wgs;
         }
@@ -725,8 +729,10 @@ int ttsweep_solve_device(ttsweep_ctx *ctx, int nstart, const ttsweep_start *star
         ctx->stats.sweeps_total += sweeps[s];
         ctx->stats.sweeps_max = std::max(ctx->stats.sweeps_max, sweeps[s]);
         // CELL kernel relaxes every cell in every pass; STRIP counts its active tiles
+        // (STRIP counts cells x offsets actually relaxed; convert to whole-star cell relaxations)
         ctx->stats.cells_relaxed += ctx->kernel == TTSWEEP_KERNEL_STRIP
-            ? (long long)ctx->h_work[2 * s] : (long long)sweeps[s] * ctx->stats.cells;
+            ? (long long)(ctx->h_work[2 * s] / std::max<size_t>(ctx->pull.size(), 1))
+            : (long long)sweeps[s] * ctx->stats.cells;
     }
     return anychange_ever ? 1 : 0;
 }

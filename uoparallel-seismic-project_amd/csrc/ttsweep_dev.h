@@ -88,6 +88,7 @@ struct StripCol {
 struct StripPlan {
     int ra, rb;                         // max |da|, max |db| over the star
     int first[2 * STRIP_MAX_RA + 2];    // columns of plane offset da are [first[da+ra], first[da+ra+1])
+    int nent[2 * STRIP_MAX_RA + 1];     // pull entries (offsets) with plane offset da
 };
 
 } // namespace ttsweep

@@ -201,22 +201,9 @@ hipError_t launch_sweep_cell(const DevLayout &L, const float *v, const StartDesc
 // +INF / 0) and no liveness tests.  The few cells that own a dead edge (inside
 // StartDesc::box) are computed but not stored; sweep_special_kernel owns them.
 
-// Workgroup-wide OR through the first words of the dynamic LDS region (no static
-// __shared__ object: it would shift the 16-byte alignment of the dynamic base).
+// Workgroup-wide reductions go through the first words of the dynamic LDS region (no
+// static __shared__ object: it would shift the 16-byte alignment of the dynamic base).
 constexpr int STRIP_LDS_HEAD = 16;      // floats reserved in front of the slabs
-__device__ __forceinline__ bool block_or(bool pred, float *smem, int wave, int lane)
-{
-    int *words = reinterpret_cast<int *>(smem);
-    __syncthreads();                    // earlier readers of the words are done
-    const unsigned long long m = __ballot(pred);
-    if (lane == 0) words[wave] = (m != 0ull);
-    __syncthreads();
-    int any = 0;
-#pragma unroll
-    for (int w = 0; w < STRIP_NS; w++) any |= words[w];
-    return any != 0;
-}
-
 
 // A column descriptor held in scalar registers.
 struct ColRegs {
@@ -246,6 +233,23 @@ __device__ __forceinline__ void pin_col(ColRegs &r)
                    "+s"(r.h[3]), "+s"(r.h[4]), "+s"(r.h[5]), "+s"(r.h[6]), "+s"(r.h[7]),
                    "+s"(r.h[8]), "+s"(r.h[9]), "+s"(r.h[10]), "+s"(r.h[11]), "+s"(r.h[12]),
                    "+s"(r.h[13]), "+s"(r.h[14]), "+s"(r.h[15]));
+}
+
+// Activity flag bits of a unit (tile_flags): something improved at all / within the
+// first / the last CF-1 cells of the strip (the only cells a neighbouring strip reads).
+enum : int { FLAG_ANY = 1, FLAG_LO = 2, FLAG_HI = 4 };
+
+// Workgroup-wide OR of one word per wave.
+__device__ __forceinline__ unsigned block_or_mask(unsigned m, float *smem, int wave, int lane)
+{
+    unsigned *words = reinterpret_cast<unsigned *>(smem);
+    __syncthreads();
+    if (lane == 0) words[wave] = m;
+    __syncthreads();
+    unsigned any = 0;
+#pragma unroll
+    for (int w = 0; w < STRIP_NS; w++) any |= words[w];
+    return any;
 }
 
 template <int K, int VARIANT>
@@ -285,29 +289,36 @@ sweep_strip_kernel(DevLayout L, const float *__restrict__ v,
     const StartDesc sd = starts[s];
     float *__restrict__ T = sd.T;
 
-    // ---- activity test, per wave.  A "unit" is what one wave relaxes: plane a x (up to)
-    // 64 cells along b x one strip of K cells along c.  It has to be relaxed in this
-    // pass only if a unit it reads from (itself and its neighbours within the star's
-    // reach: +-ra planes, +-1 lane tile, +-1 strip) improved in the previous pass.
+    // ---- activity test, per wave and per neighbour plane.  A "unit" is what one wave
+    // relaxes: plane a x (up to) 64 cells along b x one strip of K cells along c.  The
+    // offsets with plane offset da have to be relaxed in this pass only if a unit they
+    // read from (plane a+da, +-1 lane tile, +-1 strip) improved in the previous pass:
+    // everything else was already relaxed against unchanged values.
     const int cstrips = ctiles * STRIP_NS;
     const int nunits = L.n[0] * btiles * cstrips;
     const int my_cs = ct * STRIP_NS + strip;
     const int my_unit = (a * btiles + bt) * cstrips + my_cs;
     int *__restrict__ cur_flags = sd.tile_flags + parity * nunits;
-    bool wave_active;
+    unsigned my_planes = 0;     // bit ia: plane offset da = ia - ra is due for this wave
     {
         const int *__restrict__ prev_flags = sd.tile_flags + (1 - parity) * nunits;
-        int f = 0;
         for (int idx = lane; idx < 9 * (2 * plan.ra + 1); idx += 64) {
-            const int da = idx / 9 - plan.ra;
+            const int ia = idx / 9;
             const int r = idx % 9;
-            const int na = a + da, nb = bt + r / 3 - 1, nc = my_cs + r % 3 - 1;
-            if (na >= 0 && na < L.n[0] && nb >= 0 && nb < btiles && nc >= 0 && nc < cstrips)
-                f |= prev_flags[(na * btiles + nb) * cstrips + nc];
+            const int na = a + ia - plan.ra, nb = bt + r / 3 - 1, nc = my_cs + r % 3 - 1;
+            // a neighbouring strip matters only if the change was within reach (< CF
+            // cells) of the shared border: FLAG_LO / FLAG_HI say which end changed
+            const int need = (r % 3 == 0) ? FLAG_HI : (r % 3 == 2) ? FLAG_LO : FLAG_ANY;
+            if (na >= 0 && na < L.n[0] && nb >= 0 && nb < btiles && nc >= 0 && nc < cstrips
+                && (prev_flags[(na * btiles + nb) * cstrips + nc] & need))
+                my_planes |= 1u << ia;
         }
-        wave_active = __ballot(f != 0) != 0ull;
+#pragma unroll
+        for (int w = 32; w >= 1; w >>= 1) my_planes |= __shfl_xor(my_planes, w);
     }
-    if (!block_or(wave_active, smem, strip, lane)) {
+    const bool wave_active = my_planes != 0;
+    const unsigned wg_planes = block_or_mask(my_planes, smem, strip, lane);
+    if (wg_planes == 0) {
         if (lane == 0) cur_flags[my_unit] = 0;
         return;
     }
@@ -334,7 +345,7 @@ sweep_strip_kernel(DevLayout L, const float *__restrict__ v,
 
     for (int ia = 0; ia <= 2 * plan.ra; ia++) {
         const int cbeg = plan.first[ia], cend = plan.first[ia + 1];
-        if (cbeg == cend) continue;
+        if (cbeg == cend || !((wg_planes >> ia) & 1u)) continue;
         const int da = ia - plan.ra;
 
         // ---- stage plane a+da: rows b0-rb .. b0+63+rb, columns c0-CF .. c0+TC+CF-1
@@ -355,7 +366,7 @@ sweep_strip_kernel(DevLayout L, const float *__restrict__ v,
         // ---- relax every column of this plane offset.  The column descriptor lives
         // in SGPRs; the NEXT column's descriptor is requested before this column's
         // arithmetic so its scalar-load latency is hidden.
-        if (!wave_active) continue;         // this wave only helps staging
+        if (!((my_planes >> ia) & 1u)) continue;    // this wave only helps staging
         ColRegs cur = load_col(cols, cbeg);
         for (int ci = cbeg; ci < cend; ci++) {
             pin_col(cur);
@@ -407,7 +418,7 @@ sweep_strip_kernel(DevLayout L, const float *__restrict__ v,
     const int cbase = c0 + strip * K;
     const bool row_ok = lane < tb_eff && b < L.n[1];
     const bool in_box_ab = a >= sd.box_lo[0] && a <= sd.box_hi[0] && b >= sd.box_lo[1] && b <= sd.box_hi[1];
-    bool improved = false;
+    int improved = 0;           // FLAG_* bits
     if (wave_active) {
 #pragma unroll
         for (int q = 0; q < K; q++) {
@@ -415,17 +426,22 @@ sweep_strip_kernel(DevLayout L, const float *__restrict__ v,
             const bool special = in_box_ab && c >= sd.box_lo[2] && c <= sd.box_hi[2];
             if (row_ok && c < L.n[2] && !special && acc[q] < T[own + q]) {
                 T[own + q] = acc[q];
-                improved = true;
+                improved |= FLAG_ANY | (q < STRIP_CF - 1 ? FLAG_LO : 0) | (q > K - STRIP_CF ? FLAG_HI : 0);
             }
         }
     }
-    const bool any = __ballot(improved) != 0ull;
+#pragma unroll
+    for (int w = 32; w >= 1; w >>= 1) improved |= __shfl_xor(improved, w);
+    const bool any = improved != 0;
     if (lane == 0) {
-        cur_flags[my_unit] = any;
+        cur_flags[my_unit] = improved;
         if (any) atomicOr(&changed[s], 1);
         if (wave_active) {
             const int wb = min(tb_eff, L.n[1] - b0), wc = max(min(K, L.n[2] - cbase), 0);
-            atomicAdd(sd.work, (unsigned long long)(wb * wc));
+            int nent = 0;
+            for (int ia = 0; ia <= 2 * plan.ra; ia++)
+                if ((my_planes >> ia) & 1u) nent += plan.nent[ia];
+            atomicAdd(sd.work, (unsigned long long)(wb * wc) * (unsigned long long)nent);
         }
     }
 }
@@ -443,7 +459,7 @@ init_tile_flags_kernel(int *__restrict__ flags, int nunits, int start_unit)
     const int t = blockIdx.x * 256 + threadIdx.x;
     if (t >= nunits) return;
     flags[t] = 0;
-    flags[nunits + t] = (start_unit < 0 || t == start_unit) ? 1 : 0;
+    flags[nunits + t] = (start_unit < 0 || t == start_unit) ? 7 : 0;
 }
 
 hipError_t launch_init_tile_flags(const DevLayout &L, const StartDesc &sd, bool all_active,
@@ -538,7 +554,7 @@ sweep_special_kernel(DevLayout L, const float *__restrict__ v,
         const int btiles = (L.n[1] + STRIP_TB - 1) / STRIP_TB;
         const int cstrips = ((L.n[2] + STRIP_TC - 1) / STRIP_TC) * STRIP_NS;
         const int nunits = L.n[0] * btiles * cstrips;
-        sd.tile_flags[parity * nunits + (a * btiles + b / STRIP_TB) * cstrips + c / STRIP_K] = 1;
+        sd.tile_flags[parity * nunits + (a * btiles + b / STRIP_TB) * cstrips + c / STRIP_K] = 7;
     }
 }
 
