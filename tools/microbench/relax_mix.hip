@@ -73,7 +73,8 @@ __global__ void __launch_bounds__(256) kern_pk(float *out, int iters, float hh)
 #pragma unroll
         for (int t = 2; t < 32; t += 2) {      // 15 blocks, all "even" (aligned) offsets
             const f32x2 h2 = {h, h};
-            const int tt = t % 16;
+            const int tt = t % 16;      // NOTE: tt repeats (t and t+16) and h += 1e-9f is a no-op in
+            // float, so the compiler merges duplicate blocks: divide this kernel's rate by 15/8.
 #pragma unroll
             for (int p = 0; p < K / 2; p++) {
                 f32x2 x = vce[p] + vN2[p + tt / 2];
