@@ -123,6 +123,18 @@ int ttsweep_solve_device(ttsweep_ctx *ctx, int nstart, const ttsweep_start *star
 
 int ttsweep_get_stats(const ttsweep_ctx *ctx, ttsweep_stats *out);
 
+/* Multi-GPU form of ttsweep_solve for a host program: the start points are
+ * independent (serial_new/...:158-162; mpi/backup.c:351-363 runs one start per
+ * rank), so start s is solved on devices[s % ndev]; every device gets its own
+ * context and copy of the velocity volume, there is no communication while
+ * sweeping, and each device writes its converged boxes straight into the caller's
+ * host arrays.  devices may name the same GPU more than once.  Returns 1 / 0 / < 0
+ * like ttsweep_solve.  (With the boxes resident in HBM the gather is a collective
+ * instead: see bench.py / multistart.py, RCCL over xGMI.) */
+int ttsweep_solve_multi(int ndev, const int *devices, int nx, int ny, int nz,
+                        const ttsweep_fs *fs, int starstart, int starstop, const float *v_host,
+                        int nstart, const ttsweep_start *starts, float *const *tt_host);
+
 /* One-call drop-in for the reference's
  *   int sweepXYZ(int nx,int ny,int nz,int s,int starstart,int starstop)  (:198)
  * with the globals it reads passed explicitly: v = vbox.box.flat,

@@ -276,3 +276,22 @@ def test_512_grid_properties(P):
     assert np.isfinite(tt).all() and tt[tuple(starts[0])] == 0 and (tt >= 0).all()
     v = v_dev.cpu().numpy()
     assert sampled_open_edges(v, tt, offs, starts[0], 20000, 2) == 0
+
+
+def test_solve_multi_shards_starts_over_devices(P, golden24):
+    """ttsweep_solve_multi with two device slots (both GPU 0 on a one-GPU box: two
+    contexts, two host threads): every start ends bit-equal to its fixture."""
+    offs = golden24.star("818")
+    fs = P.inputs.make_fs(offs)
+    keys = ["818_mid", "818_corner", "818_deadin", "818_deadout"]
+    starts = [golden24.z[f"start_{k}"] for k in keys]
+    for devices in ([0, 0], [0, 0, 0, 0, 0]):       # more device slots than starts, too
+        tts = []
+        for st in starts:
+            tt = np.full(golden24.v.shape, np.inf, dtype=np.float32)
+            tt[tuple(st)] = 0
+            tts.append(tt)
+        assert P.solve_multi(devices, golden24.v, fs, starts, tts) == 1
+        for k, tt in zip(keys, tts):
+            assert_bit_equal(tt, golden24.z[f"tt_{k}"], k)
+        assert P.solve_multi(devices, golden24.v, fs, starts, tts) == 0

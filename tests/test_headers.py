@@ -192,3 +192,24 @@ def test_reference_reader_accepts_our_writer(tmp_path, pkg, oracle):
     out = np.zeros(v.size, np.float32)
     assert R.ttref_load_vbox(str(path).encode(), hdr, out, out.size) == 1
     assert hdr.tolist() == [2, 3, 4, 5, 4, 3] and np.array_equal(out.reshape(v.shape), v)
+
+
+def test_vconvert_tool(tmp_path, pkg):
+    """host/vconvert.c (the reference's tools/vconvert.c on the kept headers): text -> vbox."""
+    host = os.path.join(ROOT, "uoparallel-seismic-project_amd", "host")
+    exe = tmp_path / "vconvert"
+    r = subprocess.run(["gcc", "-O2", "-Wall", "-Werror", "-I", INC, "-o", str(exe),
+                        os.path.join(host, "vconvert.c")], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    shape = (4, 3, 5)
+    v = np.round(pkg.inputs.velocity_model(*shape, seed=6), 5).astype(np.float32)
+    txt = tmp_path / "m.txt"
+    txt.write_text("".join(f"{x + 1},{y + 1},{z + 1},{v[x, y, z]:.5f}\n"
+                           for x in range(4) for y in range(3) for z in range(5)))
+    r = subprocess.run([str(exe), str(txt), str(tmp_path / "m.vbox")], capture_output=True, text=True)
+    assert r.returncode == 0 and "done." in r.stdout
+    origin, got = pkg.inputs.read_vbox(str(tmp_path / "m.vbox"))
+    want = np.array([float(f"{x:.5f}") for x in v.reshape(-1)], np.float32).reshape(shape)
+    assert origin == (1, 1, 1) and np.array_equal(got, want)
+    r = subprocess.run([str(exe)], capture_output=True, text=True)
+    assert r.returncode == 0 and "usage:" in r.stdout

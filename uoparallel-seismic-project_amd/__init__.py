@@ -7,9 +7,9 @@ from . import _lib, inputs, multistart, solver
 from ._lib import (KERNEL_AUTO, KERNEL_CELL, KERNEL_STRIP, OPT_BATCH_SWEEPS, OPT_KERNEL,
                    OPT_MAX_SWEEPS, OPT_TIMING)
 from .solver import (TravelTimeSolver, TTSweepError, build_pull_star, device_count,
-                     relaxations_per_sweep, sweepXYZ)
+                     relaxations_per_sweep, solve_multi, sweepXYZ)
 
 __all__ = ["_lib", "inputs", "multistart", "solver", "TravelTimeSolver", "TTSweepError",
-           "build_pull_star", "device_count", "relaxations_per_sweep", "sweepXYZ",
+           "build_pull_star", "device_count", "relaxations_per_sweep", "solve_multi", "sweepXYZ",
            "KERNEL_AUTO", "KERNEL_CELL", "KERNEL_STRIP", "OPT_TIMING", "OPT_KERNEL",
            "OPT_MAX_SWEEPS", "OPT_BATCH_SWEEPS"]

@@ -16,6 +16,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "pullstar.h"
@@ -772,6 +773,41 @@ int ttsweep_get_stats(const ttsweep_ctx *ctx, ttsweep_stats *out)
     if (!ctx || !out) return set_error("null argument");
     *out = ctx->stats;
     return 0;
+}
+
+int ttsweep_solve_multi(int ndev, const int *devices, int nx, int ny, int nz,
+                        const ttsweep_fs *fs, int starstart, int starstop, const float *v_host,
+                        int nstart, const ttsweep_start *starts, float *const *tt_host)
+{
+    if (ndev <= 0 || !devices || !starts || !tt_host || nstart < 0) return set_error("bad arguments");
+    std::vector<int> rc(ndev, 0);
+    std::vector<std::string> err(ndev);
+    std::vector<std::thread> workers;
+    for (int d = 0; d < ndev; d++) {
+        workers.emplace_back([&, d]() {
+            std::vector<ttsweep_start> my_starts;
+            std::vector<float *> my_boxes;
+            for (int s = d; s < nstart; s += ndev) {        // round-robin shard
+                my_starts.push_back(starts[s]);
+                my_boxes.push_back(tt_host[s]);
+            }
+            if (my_starts.empty()) return;
+            ttsweep_ctx *ctx = ttsweep_create(devices[d], nx, ny, nz, fs, starstart, starstop);
+            int r = ctx ? ttsweep_set_velocity(ctx, v_host) : -1;
+            if (r == 0)
+                r = ttsweep_solve(ctx, (int)my_starts.size(), my_starts.data(), my_boxes.data());
+            if (r < 0) err[d] = ttsweep_last_error();       // thread-local text
+            ttsweep_destroy(ctx);
+            rc[d] = r;
+        });
+    }
+    for (auto &w : workers) w.join();
+    int any = 0;
+    for (int d = 0; d < ndev; d++) {
+        if (rc[d] < 0) return set_error("device %d: %s", devices[d], err[d].c_str());
+        any |= rc[d];
+    }
+    return any;
 }
 
 int ttsweep_sweepXYZ(const float *v, float *tt, int nx, int ny, int nz, const ttsweep_fs *fs,

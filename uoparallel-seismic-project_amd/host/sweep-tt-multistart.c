@@ -25,7 +25,8 @@
  * argument count is checked, and the "cannot open starting points" message
  * prints argv[3] (the reference prints argv[4], :102).
  *
- * Environment: TTSWEEP_DEVICE=<n> selects the GPU (default 0);
+ * Environment: TTSWEEP_DEVICE=<n> selects the GPU (default 0); TTSWEEP_GPUS=<N>
+ * shards the start points over GPUs 0..N-1 (ttsweep_solve_multi);
  * TTSWEEP_NO_OUTPUT=1 skips writing output.tt (2.96 M text lines per start).
  */
 #include "velocityboxfiler.h"
@@ -207,7 +208,27 @@ int sweepXYZ(int nx, int ny, int nz, int s, int starstart, int starstop)
 {
     static ttsweep_ctx *ctx = NULL;
     static int result[STARTMAX];
+    const char *gpus = getenv("TTSWEEP_GPUS");
     int n;
+
+    if (gpus != NULL && atoi(gpus) > 1) {           /* several GPUs: shard the starts */
+        if (s == 0) {
+            float *boxes[STARTMAX];
+            int devices[64], ndev = atoi(gpus), rc;
+            if (ndev > 64) ndev = 64;
+            for (n = 0; n < ndev; n++) devices[n] = n;
+            for (n = 0; n < numstart_g; n++) boxes[n] = ttboxes[n].flat;
+            rc = ttsweep_solve_multi(ndev, devices, nx, ny, nz, (const ttsweep_fs *)fs, starstart,
+                                     starstop, vbox.box.flat, numstart_g,
+                                     (const ttsweep_start *)start, boxes);
+            if (rc < 0) {
+                printf("ttsweep: %s\n", ttsweep_last_error());
+                exit(1);
+            }
+            for (n = 0; n < numstart_g; n++) result[n] = rc;
+        }
+        return result[s];
+    }
 
     if (ctx == NULL) {
         const char *dev = getenv("TTSWEEP_DEVICE");

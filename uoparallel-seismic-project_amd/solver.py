@@ -147,6 +147,26 @@ class TravelTimeSolver:
         return {name: getattr(st, name) for name, _ in Stats._fields_}
 
 
+def solve_multi(devices, v: np.ndarray, fs: np.ndarray, starts, tt_boxes, starstart: int = 0,
+                starstop: int | None = None) -> int:
+    """ttsweep_solve_multi: shard the starts round-robin over `devices` (host boxes)."""
+    v = np.ascontiguousarray(v, dtype=np.float32)
+    fs = np.ascontiguousarray(fs, dtype=FS_DTYPE)
+    if starstop is None:
+        starstop = len(fs) - 1
+    arr = TravelTimeSolver._starts_array(starts)
+    assert len(tt_boxes) == len(arr)
+    ptrs = (C.c_void_p * len(arr))()
+    for s, box in enumerate(tt_boxes):
+        assert box.dtype == np.float32 and box.flags["C_CONTIGUOUS"] and box.shape == v.shape
+        ptrs[s] = box.ctypes.data
+    dev = (C.c_int * len(devices))(*devices)
+    nx, ny, nz = v.shape
+    return _check(_lib.lib().ttsweep_solve_multi(len(devices), dev, nx, ny, nz, fs.ctypes.data,
+                                                 starstart, starstop, v.ctypes.data, len(arr), arr,
+                                                 ptrs), "ttsweep_solve_multi")
+
+
 def sweepXYZ(v: np.ndarray, tt: np.ndarray, fs: np.ndarray, start, starstart: int = 0,
              starstop: int | None = None) -> int:
     """The one-call drop-in (ttsweep_sweepXYZ): converge `tt` in place on device 0."""
