@@ -90,7 +90,7 @@ def test_resume_and_idempotence(P, golden24, oracle):
     assert_bit_equal(tt, want, "resume")
     before = tt.copy()
     (tt,), rc, st = gpu_converge(P, golden24.v, fs, [m["start"]], tts=[tt])
-    assert rc == 0 and st["sweeps_total"] == 1
+    assert rc == 0 and st["sweeps_total"] <= 2     # confirming pass (+ one speculative pass)
     assert_bit_equal(tt, before, "idempotent")
 
 
@@ -164,23 +164,25 @@ def full(P):
 
 
 def test_full_size_digests(P, full):
-    """Converged 241x241x51 boxes equal the reference's (SHA-256 recorded from the
-    reference run; start (120,120,50); includes the dead-edge cell (113,119,49))."""
-    path = os.path.join(GOLDEN, "big_digests.json")
-    digests = json.load(open(path))
-    ran = 0
-    for sname in ("3", "818"):
-        want = digests.get(f"syn241_{sname}_120_120_50")
-        if want is None:
-            continue
+    """Converged 241x241x51 boxes equal the reference's (SHA-256 recorded from runs of
+    the unmodified reference: tests/golden/big_digests.json): 3-FS and 818-FS from start
+    (120,120,50) - including the dead-edge cell (113,119,49) - and 818-FS from several
+    start points of the BASELINE start-24 file, solved as one batch."""
+    digests = json.load(open(os.path.join(GOLDEN, "big_digests.json")))
+    by_star = {}
+    for key, want in digests.items():
+        _, sname, i, j, k = key.split("_")
+        by_star.setdefault(sname, []).append(((int(i), int(j), int(k)), want))
+    assert "3" in by_star and "818" in by_star
+    for sname, cases in by_star.items():
         fs = P.inputs.make_fs(P.inputs.read_triples(P.inputs.star_path(sname)))
-        (tt,), rc, st = gpu_converge(P, full, fs, [(120, 120, 50)])
-        for pos, b in want["spots"].items():
-            p = tuple(map(int, pos.split(",")))
-            assert int(tt[p].view(np.uint32)) == b, (sname, p)
-        assert hashlib.sha256(tt.tobytes()).hexdigest() == want["sha256"], sname
-        ran += 1
-    assert ran >= 1
+        tts, rc, st = gpu_converge(P, full, fs, [c[0] for c in cases])
+        assert rc == 1
+        for tt, (start, want) in zip(tts, cases):
+            for pos, b in want["spots"].items():
+                p = tuple(map(int, pos.split(",")))
+                assert int(tt[p].view(np.uint32)) == b, (sname, start, p)
+            assert hashlib.sha256(tt.tobytes()).hexdigest() == want["sha256"], (sname, start)
 
 
 def test_full_size_fixed_point_properties(P, oracle, full):
@@ -196,7 +198,7 @@ def test_full_size_fixed_point_properties(P, oracle, full):
         assert tt[tuple(s)] == 0 and (tt >= 0).all()
     again = [t.copy() for t in tts]
     _, rc2, st2 = gpu_converge(P, full, fs, starts, tts=again)
-    assert rc2 == 0 and st2["sweeps_total"] == len(starts)
+    assert rc2 == 0 and st2["sweeps_total"] <= 2 * len(starts)
     for a, b in zip(again, tts):
         assert_bit_equal(a, b, "idempotent")
     open_edges, ninf = oracle.validate(full, tts[0], oracle.make_star(

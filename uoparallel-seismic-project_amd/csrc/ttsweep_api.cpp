@@ -52,6 +52,10 @@ static int set_error(const char *fmt, ...)
 // ---------------------------------------------------------------------------
 // context
 // ---------------------------------------------------------------------------
+// Passes are enqueued one ahead of the convergence test (see ttsweep_solve_device), so the
+// per-start "changed" words exist once per pass in flight.
+constexpr int PASS_SLOTS = 3;
+
 struct ttsweep_ctx {
     int device = 0;
     int nx = 0, ny = 0, nz = 0;
@@ -101,6 +105,7 @@ struct ttsweep_ctx {
     int batch_sweeps = 1;
 
     hipEvent_t ev_solve0 = nullptr, ev_solve1 = nullptr;
+    hipEvent_t ev_flags[PASS_SLOTS] = {nullptr, nullptr, nullptr};     // "changed" words of a pass are on the host
     std::vector<hipEvent_t> ev_pool;        // pairs around sweep launches
     size_t ev_used = 0;
 
@@ -309,10 +314,10 @@ static int ensure_capacity(ttsweep_ctx *ctx, int nstart)
     HIPCHK(hipMalloc((void **)&ctx->d_T, (size_t)nstart * ctx->L.cells * sizeof(float)));
     HIPCHK(hipMalloc((void **)&ctx->d_starts, nstart * sizeof(StartDesc)));
     HIPCHK(hipMalloc((void **)&ctx->d_active, nstart * sizeof(int)));
-    HIPCHK(hipMalloc((void **)&ctx->d_changed, nstart * sizeof(int)));
+    HIPCHK(hipMalloc((void **)&ctx->d_changed, PASS_SLOTS * nstart * sizeof(int)));
     HIPCHK(hipHostMalloc((void **)&ctx->h_starts, nstart * sizeof(StartDesc)));
     HIPCHK(hipHostMalloc((void **)&ctx->h_active, nstart * sizeof(int)));
-    HIPCHK(hipHostMalloc((void **)&ctx->h_changed, nstart * sizeof(int)));
+    HIPCHK(hipHostMalloc((void **)&ctx->h_changed, PASS_SLOTS * nstart * sizeof(int)));
     HIPCHK(hipMalloc((void **)&ctx->d_tile_flags,
                      (size_t)nstart * 2 * std::max(strip_units(ctx->L), 1) * sizeof(int)));
     HIPCHK(hipMalloc((void **)&ctx->d_work, 2 * nstart * sizeof(unsigned long long)));
@@ -410,20 +415,20 @@ static void order_tiles(const ttsweep_ctx *ctx, const StartDesc &sd, std::vector
 }
 
 // One full-grid pass for the active starts.
-static int launch_pass(ttsweep_ctx *ctx, int nactive)
+static int launch_pass(ttsweep_ctx *ctx, int nactive, int *d_changed)
 {
     hipEvent_t e0, e1;
     if (ctx->timing && timed_event(ctx, &e0)) return -1;
     if (ctx->kernel == TTSWEEP_KERNEL_STRIP) {
         HIPCHK(launch_sweep_strip(ctx->L, ctx->d_v, ctx->d_starts, ctx->d_worklist,
-                                  ctx->worklist_len, ctx->d_changed, ctx->d_strip_cols, ctx->plan,
+                                  ctx->worklist_len, d_changed, ctx->d_strip_cols, ctx->plan,
                                   ctx->pass_index & 1, ctx->stream));
         HIPCHK(launch_sweep_special(ctx->L, ctx->d_v, ctx->d_starts, ctx->d_active, nactive,
-                                    ctx->d_changed, ctx->d_cell_entries, ctx->n_cell_entries,
+                                    d_changed, ctx->d_cell_entries, ctx->n_cell_entries,
                                     ctx->max_box_cells, ctx->pass_index & 1, ctx->stream));
     } else {
         HIPCHK(launch_sweep_cell(ctx->L, ctx->d_v, ctx->d_starts, ctx->d_active, nactive,
-                                 ctx->d_changed, ctx->d_cell_entries, ctx->n_cell_entries,
+                                 d_changed, ctx->d_cell_entries, ctx->n_cell_entries,
                                  ctx->stream));
     }
     if (ctx->timing && timed_event(ctx, &e1)) return -1;
@@ -505,6 +510,9 @@ ttsweep_ctx *ttsweep_create(int device, int nx, int ny, int nz, const ttsweep_fs
            && hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) == hipSuccess
            && hipEventCreate(&ctx->ev_solve0) == hipSuccess
            && hipEventCreate(&ctx->ev_solve1) == hipSuccess
+           && hipEventCreateWithFlags(&ctx->ev_flags[0], hipEventDisableTiming) == hipSuccess
+           && hipEventCreateWithFlags(&ctx->ev_flags[1], hipEventDisableTiming) == hipSuccess
+           && hipEventCreateWithFlags(&ctx->ev_flags[2], hipEventDisableTiming) == hipSuccess
            && hipMalloc((void **)&ctx->d_v, (size_t)ctx->L.cells * sizeof(float)) == hipSuccess;
     if (!ok) {
         set_error("ttsweep_create: HIP setup failed: %s", hipGetErrorString(hipGetLastError()));
@@ -540,6 +548,8 @@ void ttsweep_destroy(ttsweep_ctx *ctx)
     for (hipEvent_t e : ctx->ev_pool) (void)hipEventDestroy(e);
     if (ctx->ev_solve0) (void)hipEventDestroy(ctx->ev_solve0);
     if (ctx->ev_solve1) (void)hipEventDestroy(ctx->ev_solve1);
+    for (hipEvent_t e : ctx->ev_flags)
+        if (e) (void)hipEventDestroy(e);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }
@@ -664,52 +674,78 @@ int ttsweep_solve_device(ttsweep_ctx *ctx, int nstart, const ttsweep_start *star
     ctx->pass_index = 0;
     if (ctx->kernel == TTSWEEP_KERNEL_STRIP && build_worklist(ctx, nstart)) return -1;
 
-    // driver loop: serial_new/...:151-170 without the break (:168-169)
+    // driver loop: serial_new/...:151-170 without the break (:168-169).  Passes are
+    // enqueued ONE AHEAD of the convergence test: pass k+1 is already running while the
+    // host waits for the "changed" words of pass k, so the GPU never idles between
+    // passes.  A start whose pass-k words show no change is converged; the pass k+1
+    // that was launched speculatively for it finds all its units inactive.
     std::vector<int> sweeps(nstart, 0);
     const bool trace = getenv("TTSWEEP_TRACE") != nullptr;
     unsigned long long trace_prev = 0, trace_prev_wg = 0;
-    int nactive = nstart;
+    std::vector<int> snapshot[PASS_SLOTS];      // active starts of each pass in flight
+    int nactive = nstart, launched = 0, processed = 0;
     bool anychange_ever = false;
-    while (nactive > 0) {
-        const auto t_pass = std::chrono::steady_clock::now();
-        HIPCHK(hipMemsetAsync(ctx->d_changed, 0, nstart * sizeof(int), ctx->stream));
-        if (launch_pass(ctx, nactive)) return -1;
-        HIPCHK(hipMemcpyAsync(ctx->h_changed, ctx->d_changed, nstart * sizeof(int),
-                              hipMemcpyDeviceToHost, ctx->stream));
-        if (trace)
-            HIPCHK(hipMemcpyAsync(ctx->h_work, ctx->d_work, 2 * nstart * sizeof(unsigned long long),
+    auto t_pass = std::chrono::steady_clock::now();
+    while (processed < launched || nactive > 0) {
+        if (nactive > 0 && launched - processed < 2) {          // enqueue the next pass
+            const int slot = launched % PASS_SLOTS;
+            int *dch = ctx->d_changed + (size_t)slot * nstart;
+            HIPCHK(hipMemsetAsync(dch, 0, nstart * sizeof(int), ctx->stream));
+            if (launch_pass(ctx, nactive, dch)) return -1;
+            HIPCHK(hipMemcpyAsync(ctx->h_changed + (size_t)slot * nstart, dch, nstart * sizeof(int),
                                   hipMemcpyDeviceToHost, ctx->stream));
-        HIPCHK(hipStreamSynchronize(ctx->stream));
-        if (trace) {    // TTSWEEP_TRACE=1: per-pass activity on stderr
+            HIPCHK(hipEventRecord(ctx->ev_flags[slot], ctx->stream));
+            snapshot[slot].assign(ctx->h_active, ctx->h_active + nactive);
+            launched++;
+            if (launched - processed < 2 && nactive > 0 && launched == 1) continue;   // prime the pipeline
+        }
+        // examine the oldest pass in flight
+        const int slot = processed % PASS_SLOTS;
+        HIPCHK(hipEventSynchronize(ctx->ev_flags[slot]));
+        const int *hch = ctx->h_changed + (size_t)slot * nstart;
+        if (trace) {    // TTSWEEP_TRACE=1: per-pass activity on stderr (serialises the passes)
+            HIPCHK(hipStreamSynchronize(ctx->stream));
+            HIPCHK(hipMemcpy(ctx->h_work, ctx->d_work, 2 * nstart * sizeof(unsigned long long),
+                             hipMemcpyDeviceToHost));
             unsigned long long tot = 0, wgs = 0;
             for (int s = 0; s < nstart; s++) { tot += ctx->h_work[2 * s]; wgs += ctx->h_work[2 * s + 1]; }
             const double us = std::chrono::duration<double, std::micro>(
                                   std::chrono::steady_clock::now() - t_pass).count();
+            t_pass = std::chrono::steady_clock::now();
             fprintf(stderr, "ttsweep pass %d: %d active starts, %.3f full-sweep equivalents relaxed, "
-                    "%llu workgroups ran, %.0f us\n", ctx->pass_index, nactive,
+                    "%llu workgroups ran, %.0f us\n", processed + 1, (int)snapshot[slot].size(),
                     (double)(tot - trace_prev) / (double)ctx->stats.cells
                         / (double)std::max<size_t>(ctx->pull.size(), 1),
                     wgs - trace_prev_wg, us);
             trace_prev = tot;
             trace_prev_wg = wgs;
         }
-        int keep = 0;
-        for (int a = 0; a < nactive; a++) {
-            const int s = ctx->h_active[a];
+        bool dropped = false;
+        for (int s : snapshot[slot]) {
             sweeps[s]++;
-            if (ctx->h_changed[s]) {
+            if (hch[s]) {
                 anychange_ever = true;
                 if (sweeps[s] >= ctx->max_sweeps)
                     return set_error("start %d did not converge in %lld sweeps", s, ctx->max_sweeps);
-                ctx->h_active[keep++] = s;
+            } else {
+                // converged: remove it from the active list (it may already be gone)
+                int *end = std::remove(ctx->h_active, ctx->h_active + nactive, s);
+                if (end != ctx->h_active + nactive) dropped = true;
+                nactive = (int)(end - ctx->h_active);
             }
         }
-        if (keep != nactive && keep > 0) {
-            HIPCHK(hipMemcpyAsync(ctx->d_active, ctx->h_active, keep * sizeof(int),
+        processed++;
+        if (dropped && nactive > 0) {
+            // (the uploads are stream-ordered behind the pass in flight; the stream is
+            // synchronised before h_active is touched again)
+            HIPCHK(hipMemcpyAsync(ctx->d_active, ctx->h_active, nactive * sizeof(int),
                                   hipMemcpyHostToDevice, ctx->stream));
-            if (ctx->kernel == TTSWEEP_KERNEL_STRIP && build_worklist(ctx, keep)) return -1;
+            if (ctx->kernel == TTSWEEP_KERNEL_STRIP) {
+                if (build_worklist(ctx, nactive)) return -1;
+            } else {
+                HIPCHK(hipStreamSynchronize(ctx->stream));
+            }
         }
-        nactive = keep;
     }
 
     for (int s = 0; s < nstart; s++)
