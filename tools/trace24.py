@@ -3,7 +3,7 @@ sys.path.insert(0,'/root/repo')
 import ttsweep_pkg; P=ttsweep_pkg.load()
 v=P.inputs.velocity_model(241,241,51,20160507)
 fs=P.inputs.make_fs(P.inputs.read_triples(P.inputs.star_path('818')))
-starts=P.inputs.read_triples(P.inputs.starts_path('24'))
+starts=P.inputs.read_triples(P.inputs.starts_path('24'))[:int(__import__('os').environ.get('NST','24'))]
 dev=torch.device('cuda:0')
 with P.TravelTimeSolver(v.shape,fs) as sol:
     sol.set_velocity(torch.from_numpy(v).to(dev))

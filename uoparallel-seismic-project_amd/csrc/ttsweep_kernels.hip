@@ -208,7 +208,7 @@ constexpr int STRIP_LDS_HEAD = 16;      // floats reserved in front of the slabs
 // A column descriptor held in scalar registers.
 struct ColRegs {
     int rowoff;
-    unsigned mask, chunks;
+    unsigned mask, chunks, chunks_small;
     float h[16];
 };
 
@@ -219,6 +219,7 @@ __device__ __forceinline__ ColRegs load_col(const StripCol *__restrict__ cols, i
     r.rowoff = c.rowoff;
     r.mask = c.mask;
     r.chunks = c.chunks;
+    r.chunks_small = c.chunks_small;
 #pragma unroll
     for (int t = 0; t < 16; t++) r.h[t] = c.h[t];
     return r;
@@ -229,7 +230,7 @@ __device__ __forceinline__ ColRegs load_col(const StripCol *__restrict__ cols, i
 __device__ __forceinline__ void pin_col(ColRegs &r)
 {
     asm volatile("; column descriptor resident"
-                 : "+s"(r.rowoff), "+s"(r.mask), "+s"(r.chunks), "+s"(r.h[1]), "+s"(r.h[2]),
+                 : "+s"(r.rowoff), "+s"(r.mask), "+s"(r.chunks), "+s"(r.chunks_small), "+s"(r.h[1]), "+s"(r.h[2]),
                    "+s"(r.h[3]), "+s"(r.h[4]), "+s"(r.h[5]), "+s"(r.h[6]), "+s"(r.h[7]),
                    "+s"(r.h[8]), "+s"(r.h[9]), "+s"(r.h[10]), "+s"(r.h[11]), "+s"(r.h[12]),
                    "+s"(r.h[13]), "+s"(r.h[14]), "+s"(r.h[15]));
@@ -240,6 +241,7 @@ __device__ __forceinline__ void pin_col(ColRegs &r)
 enum : int { FLAG_ANY = 1, FLAG_LO = 2, FLAG_HI = 4 };
 
 // Workgroup-wide OR of one word per wave.
+template <int NS>
 __device__ __forceinline__ unsigned block_or_mask(unsigned m, float *smem, int wave, int lane)
 {
     unsigned *words = reinterpret_cast<unsigned *>(smem);
@@ -248,20 +250,25 @@ __device__ __forceinline__ unsigned block_or_mask(unsigned m, float *smem, int w
     __syncthreads();
     unsigned any = 0;
 #pragma unroll
-    for (int w = 0; w < STRIP_NS; w++) any |= words[w];
+    for (int w = 0; w < NS; w++) any |= words[w];
     return any;
 }
 
-template <int K, int VARIANT>
-__global__ void __launch_bounds__(STRIP_TB *STRIP_NS, 3)
+// K cells per lane (strip length); the tile is always STRIP_TC cells wide, so a
+// workgroup has STRIP_TC / K waves.  K = 16: least overhead per relaxation (default).
+// K = 8: twice as many, half as long, units - used when there are few starts, where
+// the length of one workgroup's critical path, not throughput, sets the pass time.
+template <int K>
+__global__ void __launch_bounds__(STRIP_TB *(STRIP_TC / K), (K == 16 ? 3 : 4))
 sweep_strip_kernel(DevLayout L, const float *__restrict__ v,
                    const StartDesc *__restrict__ starts, const int2 *__restrict__ work,
                    int *__restrict__ changed, const StripCol *__restrict__ cols,
                    StripPlan plan, int btiles, int ctiles, int parity)
 {
-    static_assert(K == STRIP_K, "geometry constants assume K == STRIP_K");
+    static_assert(STRIP_TC % K == 0 && K % 4 == 0, "strips must tile the workgroup tile");
+    constexpr int NS = STRIP_TC / K;            // waves (strips) per workgroup
     constexpr int W = K + 2 * STRIP_CF;
-    constexpr int NT = STRIP_TB * STRIP_NS;
+    constexpr int NT = STRIP_TB * NS;
     extern __shared__ __attribute__((aligned(16))) float smem[];
 
     // Block -> (start, tile) through a host-built work list (see build_worklist in
@@ -294,9 +301,9 @@ sweep_strip_kernel(DevLayout L, const float *__restrict__ v,
     // offsets with plane offset da have to be relaxed in this pass only if a unit they
     // read from (plane a+da, +-1 lane tile, +-1 strip) improved in the previous pass:
     // everything else was already relaxed against unchanged values.
-    const int cstrips = ctiles * STRIP_NS;
+    const int cstrips = ctiles * NS;
     const int nunits = L.n[0] * btiles * cstrips;
-    const int my_cs = ct * STRIP_NS + strip;
+    const int my_cs = ct * NS + strip;
     const int my_unit = (a * btiles + bt) * cstrips + my_cs;
     int *__restrict__ cur_flags = sd.tile_flags + parity * nunits;
     unsigned my_planes = 0;     // bit ia: plane offset da = ia - ra is due for this wave
@@ -317,7 +324,7 @@ sweep_strip_kernel(DevLayout L, const float *__restrict__ v,
         for (int w = 32; w >= 1; w >>= 1) my_planes |= __shfl_xor(my_planes, w);
     }
     const bool wave_active = my_planes != 0;
-    const unsigned wg_planes = block_or_mask(my_planes, smem, strip, lane);
+    const unsigned wg_planes = block_or_mask<NS>(my_planes, smem, strip, lane);
     if (wg_planes == 0) {
         if (lane == 0) cur_flags[my_unit] = 0;
         return;
@@ -372,7 +379,7 @@ sweep_strip_kernel(DevLayout L, const float *__restrict__ v,
             pin_col(cur);
             const ColRegs nxt = load_col(cols, min(ci + 1, cend - 1));
             const int off = (lane_r + rb + cur.rowoff) * STRIP_PW + strip * K;
-            const unsigned chunks = cur.chunks;
+            const unsigned chunks = (K == STRIP_K) ? cur.chunks : cur.chunks_small;
             const unsigned mask = cur.mask;
             float vN[W], tN[W];
 #pragma unroll
@@ -387,9 +394,8 @@ sweep_strip_kernel(DevLayout L, const float *__restrict__ v,
 #pragma unroll
             for (int t = 1; t < 2 * STRIP_CF; t++) {
                 if (mask & (1u << t)) {
-                    float h = cur.h[t];
-                    if (VARIANT & 1)    // a VGPR copy: VALU ops with an SGPR operand issue at half rate
-                        asm volatile("v_mov_b32 %0, %1" : "=v"(h) : "s"(cur.h[t]));
+                    float h;    // a VGPR copy: VALU ops with an SGPR operand issue at half rate
+                    asm volatile("v_mov_b32 %0, %1" : "=v"(h) : "s"(cur.h[t]));
                     // G independent relaxations are kept in flight: written as one
                     // add/mul/add/min chain per cell the compiler serialises them on a
                     // single temporary and every VALU op waits for its predecessor
@@ -451,7 +457,7 @@ int strip_tiles(const DevLayout &L)
     return L.n[0] * ((L.n[1] + STRIP_TB - 1) / STRIP_TB) * ((L.n[2] + STRIP_TC - 1) / STRIP_TC);
 }
 
-int strip_units(const DevLayout &L) { return strip_tiles(L) * STRIP_NS; }
+int strip_units(const DevLayout &L, int k) { return strip_tiles(L) * (STRIP_TC / k); }
 
 __global__ void __launch_bounds__(256)
 init_tile_flags_kernel(int *__restrict__ flags, int nunits, int start_unit)
@@ -463,14 +469,14 @@ init_tile_flags_kernel(int *__restrict__ flags, int nunits, int start_unit)
 }
 
 hipError_t launch_init_tile_flags(const DevLayout &L, const StartDesc &sd, bool all_active,
-                                  hipStream_t st)
+                                  int k, hipStream_t st)
 {
     const int btiles = (L.n[1] + STRIP_TB - 1) / STRIP_TB;
     const int ctiles = (L.n[2] + STRIP_TC - 1) / STRIP_TC;
-    const int cstrips = ctiles * STRIP_NS;
+    const int cstrips = ctiles * (STRIP_TC / k);
     const int nunits = L.n[0] * btiles * cstrips;
     const int start_unit = all_active ? -1
-        : (sd.sa * btiles + sd.sb / STRIP_TB) * cstrips + sd.sc / STRIP_K;
+        : (sd.sa * btiles + sd.sb / STRIP_TB) * cstrips + sd.sc / k;
     hipLaunchKernelGGL(init_tile_flags_kernel, dim3((nunits + 255) / 256), dim3(256), 0, st,
                        sd.tile_flags, nunits, start_unit);
     return hipGetLastError();
@@ -482,27 +488,35 @@ size_t strip_lds_bytes(const StripPlan &plan, int nb)
          * sizeof(float);
 }
 
-hipError_t launch_sweep_strip(const DevLayout &L, const float *v, const StartDesc *starts,
-                              const int2 *work, long long nblocks, int *changed,
-                              const StripCol *cols, const StripPlan &plan, int parity,
-                              hipStream_t st)
+template <int K>
+static hipError_t launch_strip_k(const DevLayout &L, const float *v, const StartDesc *starts,
+                                 const int2 *work, long long nblocks, int *changed,
+                                 const StripCol *cols, const StripPlan &plan, int parity,
+                                 hipStream_t st)
 {
     const int btiles = (L.n[1] + STRIP_TB - 1) / STRIP_TB;
     const int ctiles = (L.n[2] + STRIP_TC - 1) / STRIP_TC;
-    if (nblocks <= 0) return hipSuccess;
-    if (nblocks > 0x7fffffffLL) return hipErrorInvalidValue;
-    static const int variant = getenv("TTSWEEP_VARIANT") ? atoi(getenv("TTSWEEP_VARIANT")) : 1;
-    auto kern = sweep_strip_kernel<STRIP_K, 1>;
-    if (variant == 0) kern = sweep_strip_kernel<STRIP_K, 0>;
+    auto kern = sweep_strip_kernel<K>;
     const size_t lds = strip_lds_bytes(plan, L.n[1]);
     if (lds > 48 * 1024) {      // above the default dynamic-LDS limit
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
     }
-    hipLaunchKernelGGL(kern, dim3((unsigned)nblocks), dim3(STRIP_TB, STRIP_NS), lds, st, L, v,
+    hipLaunchKernelGGL(kern, dim3((unsigned)nblocks), dim3(STRIP_TB, STRIP_TC / K), lds, st, L, v,
                        starts, work, changed, cols, plan, btiles, ctiles, parity);
     return hipGetLastError();
+}
+
+hipError_t launch_sweep_strip(const DevLayout &L, const float *v, const StartDesc *starts,
+                              const int2 *work, long long nblocks, int k, int *changed,
+                              const StripCol *cols, const StripPlan &plan, int parity,
+                              hipStream_t st)
+{
+    if (nblocks <= 0) return hipSuccess;
+    if (nblocks > 0x7fffffffLL) return hipErrorInvalidValue;
+    if (k == 8) return launch_strip_k<8>(L, v, starts, work, nblocks, changed, cols, plan, parity, st);
+    return launch_strip_k<STRIP_K>(L, v, starts, work, nblocks, changed, cols, plan, parity, st);
 }
 
 // ===========================================================================
@@ -516,7 +530,7 @@ __global__ void __launch_bounds__(64)
 sweep_special_kernel(DevLayout L, const float *__restrict__ v,
                      const StartDesc *__restrict__ starts, const int *__restrict__ active,
                      int *__restrict__ changed, const CellEntry *__restrict__ entries,
-                     int nentries, int max_box_cells, int parity)
+                     int nentries, int max_box_cells, int parity, int k)
 {
     const int s = active[blockIdx.x / max_box_cells];
     int cell = blockIdx.x % max_box_cells;
@@ -552,20 +566,20 @@ sweep_special_kernel(DevLayout L, const float *__restrict__ v,
         atomicOr(&changed[s], 1);
         // runs after the STRIP pass of the same parity has written its tile flags
         const int btiles = (L.n[1] + STRIP_TB - 1) / STRIP_TB;
-        const int cstrips = ((L.n[2] + STRIP_TC - 1) / STRIP_TC) * STRIP_NS;
+        const int cstrips = ((L.n[2] + STRIP_TC - 1) / STRIP_TC) * (STRIP_TC / k);
         const int nunits = L.n[0] * btiles * cstrips;
-        sd.tile_flags[parity * nunits + (a * btiles + b / STRIP_TB) * cstrips + c / STRIP_K] = 7;
+        sd.tile_flags[parity * nunits + (a * btiles + b / STRIP_TB) * cstrips + c / k] = 7;
     }
 }
 
 hipError_t launch_sweep_special(const DevLayout &L, const float *v, const StartDesc *starts,
                                 const int *active, int nactive, int *changed,
                                 const CellEntry *entries, int nentries, int max_box_cells,
-                                int parity, hipStream_t st)
+                                int parity, int k, hipStream_t st)
 {
     if (nactive <= 0 || max_box_cells <= 0) return hipSuccess;
     hipLaunchKernelGGL(sweep_special_kernel, dim3((unsigned)(nactive * max_box_cells)), dim3(64), 0,
-                       st, L, v, starts, active, changed, entries, nentries, max_box_cells, parity);
+                       st, L, v, starts, active, changed, entries, nentries, max_box_cells, parity, k);
     return hipGetLastError();
 }
 
