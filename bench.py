@@ -58,6 +58,20 @@ def cpu_baseline(P, v, offs, start, sweeps=4):
                       f"(single thread, gcc -O3; host has {os.cpu_count()} logical cores)"}
 
 
+def measured_traffic():
+    """HBM-side bytes per sweep-kernel launch from the rocprofv3 PMC passes of this same
+    command (FETCH_SIZE and WRITE_SIZE in separate runs, gfx950 x2 read correction),
+    committed under profiles/; bench.py cannot run a profiler around itself."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")))
+    if not files:
+        return None
+    try:
+        return float(json.load(open(files[-1]))["bytes_per_launch"])
+    except Exception:
+        return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -94,6 +108,8 @@ def main():
             dist.init_process_group(args.backend)
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
 
+    default_workload = (args.grid, args.star, args.starts, args.nstarts, args.kernel) == \
+        ("241,241,51", "818", "24", 0, 0) and world == 1
     nx, ny, nz = map(int, args.grid.split(","))
     cells = nx * ny * nz
     offs = P.inputs.read_triples(P.inputs.star_path(args.star))
@@ -185,7 +201,8 @@ def main():
                        "passes_per_start_mean": sweeps_all / args.steps / nstart,
                        "full_sweep_equivalents_per_start_mean": relaxed_all / cells / args.steps / nstart},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS,
+                         "traffic": measured_traffic() if default_workload else None,
                          "kernel": "sweep", "launches": int(launches),
                          "avg_launch_ms": st["sweep_kernel_ms"] / launches,
                          "algorithmic_bytes_per_launch": alg_bytes / launches,
