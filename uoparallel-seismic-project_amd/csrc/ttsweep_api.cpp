@@ -80,8 +80,6 @@ struct ttsweep_ctx {
     std::vector<std::array<int, 3>> special_offsets;   // device-axis offsets e: cell start - e owns a dead edge
     bool start_is_special = false;
     int max_box_cells = 0;                  // of the current solve
-    int strip_k = STRIP_K;                  // strip length of the current solve (16 or 8)
-    long long short_strip_below = 8000;     // use strips of 8 when starts x tiles is below this
     int2 *d_worklist = nullptr;             // STRIP: block -> (start, tile)
     size_t worklist_cap = 0;
     long long worklist_len = 0;
@@ -217,10 +215,8 @@ static int upload_strip_plan(ttsweep_ctx *ctx)
         }
         col->mask |= 1u << t;
         col->h[t] = e.h;
-        for (int j = 0; j < STRIP_W / 4; j++) {    // window floats t .. t+K-1 are read
+        for (int j = 0; j < STRIP_W / 4; j++)      // window floats t .. t+K-1 are read
             if (4 * j + 3 >= t && 4 * j <= t + STRIP_K - 1) col->chunks |= 1u << j;
-            if (4 * j + 3 >= t && 4 * j <= t + 8 - 1) col->chunks_small |= 1u << j;
-        }
     }
     std::vector<StripCol> flat;
     for (int ia = 0; ia <= 2 * plan.ra; ia++) {
@@ -323,7 +319,7 @@ static int ensure_capacity(ttsweep_ctx *ctx, int nstart)
     HIPCHK(hipHostMalloc((void **)&ctx->h_active, nstart * sizeof(int)));
     HIPCHK(hipHostMalloc((void **)&ctx->h_changed, PASS_SLOTS * nstart * sizeof(int)));
     HIPCHK(hipMalloc((void **)&ctx->d_tile_flags,
-                     (size_t)nstart * 2 * std::max(strip_units(ctx->L, 8), 1) * sizeof(int)));
+                     (size_t)nstart * 2 * std::max(strip_units(ctx->L), 1) * sizeof(int)));
     HIPCHK(hipMalloc((void **)&ctx->d_work, 2 * nstart * sizeof(unsigned long long)));
     HIPCHK(hipHostMalloc((void **)&ctx->h_work, 2 * nstart * sizeof(unsigned long long)));
     ctx->capacity_starts = nstart;
@@ -425,12 +421,11 @@ static int launch_pass(ttsweep_ctx *ctx, int nactive, int *d_changed)
     if (ctx->timing && timed_event(ctx, &e0)) return -1;
     if (ctx->kernel == TTSWEEP_KERNEL_STRIP) {
         HIPCHK(launch_sweep_strip(ctx->L, ctx->d_v, ctx->d_starts, ctx->d_worklist,
-                                  ctx->worklist_len, ctx->strip_k, d_changed, ctx->d_strip_cols,
-                                  ctx->plan, ctx->pass_index & 1, ctx->stream));
+                                  ctx->worklist_len, d_changed, ctx->d_strip_cols, ctx->plan,
+                                  ctx->pass_index & 1, ctx->stream));
         HIPCHK(launch_sweep_special(ctx->L, ctx->d_v, ctx->d_starts, ctx->d_active, nactive,
                                     d_changed, ctx->d_cell_entries, ctx->n_cell_entries,
-                                    ctx->max_box_cells, ctx->pass_index & 1, ctx->strip_k,
-                                    ctx->stream));
+                                    ctx->max_box_cells, ctx->pass_index & 1, ctx->stream));
     } else {
         HIPCHK(launch_sweep_cell(ctx->L, ctx->d_v, ctx->d_starts, ctx->d_active, nactive,
                                  d_changed, ctx->d_cell_entries, ctx->n_cell_entries,
@@ -641,12 +636,6 @@ int ttsweep_solve_device(ttsweep_ctx *ctx, int nstart, const ttsweep_start *star
 
     const DevLayout &L = ctx->L;
     HIPCHK(hipEventRecord(ctx->ev_solve0, ctx->stream));
-    if (ctx->kernel == TTSWEEP_KERNEL_STRIP) {
-        // few starts: the pass time is set by the critical path of one workgroup, not by
-        // throughput -> halve the strips (twice the waves, half the work each)
-        ctx->strip_k = (long long)nstart * strip_tiles(L) < ctx->short_strip_below ? 8 : STRIP_K;
-        if (const char *env = getenv("TTSWEEP_STRIP_K")) ctx->strip_k = atoi(env) == 8 ? 8 : STRIP_K;
-    }
 
     for (int s = 0; s < nstart; s++) {
         const int u[3] = {starts[s].i, starts[s].j, starts[s].k};
@@ -666,12 +655,12 @@ int ttsweep_solve_device(ttsweep_ctx *ctx, int nstart, const ttsweep_start *star
             for (int d = 0; d < 3; d++) vol *= std::max(sd.box_hi[d] - sd.box_lo[d] + 1, 0);
             ctx->max_box_cells = std::max<long long>(s == 0 ? 0 : ctx->max_box_cells, vol);
         }
-        sd.tile_flags = ctx->d_tile_flags + (size_t)s * 2 * std::max(strip_units(L, 8), 1);
+        sd.tile_flags = ctx->d_tile_flags + (size_t)s * 2 * std::max(strip_units(L), 1);
         sd.work = ctx->d_work + 2 * s;
         if (init) HIPCHK(launch_init_tt(L, sd.T, sd.sidx, ctx->stream));
         else HIPCHK(launch_pack(L, tt_dev[s], sd.T, INFINITY, ctx->stream));
         if (ctx->kernel == TTSWEEP_KERNEL_STRIP) {
-            HIPCHK(launch_init_tile_flags(L, sd, /*all_active=*/!init, ctx->strip_k, ctx->stream));
+            HIPCHK(launch_init_tile_flags(L, sd, /*all_active=*/!init, ctx->stream));
             if ((int)ctx->tile_order.size() < nstart) ctx->tile_order.resize(nstart);
             order_tiles(ctx, sd, ctx->tile_order[s]);
         }

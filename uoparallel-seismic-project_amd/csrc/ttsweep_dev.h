@@ -80,8 +80,8 @@ constexpr int STRIP_MAX_RA = 7;                     // plane offsets handled: |d
 struct StripCol {
     int rowoff;             // db: row offset inside the staged slab
     unsigned mask;          // bit t (1..15) set: offset dc = t - 8 is present
-    unsigned chunks;        // bit j set: float4 j of the window is needed (strip length STRIP_K)
-    unsigned chunks_small;  // the same for the short-strip kernel (strip length 8)
+    unsigned chunks;        // bit j set: float4 j of the window is needed
+    int pad_;
     float h[16];            // h[t] = d/2 of offset (da, db, t-8)
 };
 

@@ -35,19 +35,19 @@ hipError_t launch_sweep_cell(const DevLayout &L, const float *v, const StartDesc
 // k-1; `parity` = k & 1 selects which half of StartDesc::tile_flags is written.
 size_t strip_lds_bytes(const StripPlan &plan, int nb);
 int strip_tiles(const DevLayout &L);            // workgroup tiles per start
-int strip_units(const DevLayout &L, int k);     // activity units (one per wave) per start, strip length k
+int strip_units(const DevLayout &L);            // activity units (one per wave) per start
 // work[b] = (start index, tile id) of block b, tile id = (a*btiles + bt)*ctiles + ct,
 // or tile id < 0 for a padding entry.
 hipError_t launch_sweep_strip(const DevLayout &L, const float *v, const StartDesc *starts,
-                              const int2 *work, long long nblocks, int k, int *changed,
+                              const int2 *work, long long nblocks, int *changed,
                               const StripCol *cols, const StripPlan &plan, int parity,
                               hipStream_t st);
 hipError_t launch_sweep_special(const DevLayout &L, const float *v, const StartDesc *starts,
                                 const int *active, int nactive, int *changed,
                                 const CellEntry *entries, int nentries, int max_box_cells,
-                                int parity, int k, hipStream_t st);
+                                int parity, hipStream_t st);
 // flags[1][*] = all_active ? 1 : (tile == start's tile); flags[0][*] = 0
 hipError_t launch_init_tile_flags(const DevLayout &L, const StartDesc &sd, bool all_active,
-                                  int k, hipStream_t st);
+                                  hipStream_t st);
 
 } // namespace ttsweep

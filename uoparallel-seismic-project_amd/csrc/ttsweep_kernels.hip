@@ -210,7 +210,7 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 // A column descriptor held in scalar registers.
 struct ColRegs {
     int rowoff;
-    unsigned mask, chunks, chunks_small;
+    unsigned mask, chunks;
     float h[16];
 };
 
@@ -221,7 +221,6 @@ __device__ __forceinline__ ColRegs load_col(const StripCol *__restrict__ cols, i
     r.rowoff = c.rowoff;
     r.mask = c.mask;
     r.chunks = c.chunks;
-    r.chunks_small = c.chunks_small;
 #pragma unroll
     for (int t = 0; t < 16; t++) r.h[t] = c.h[t];
     return r;
@@ -232,7 +231,7 @@ __device__ __forceinline__ ColRegs load_col(const StripCol *__restrict__ cols, i
 __device__ __forceinline__ void pin_col(ColRegs &r)
 {
     asm volatile("; column descriptor resident"
-                 : "+s"(r.rowoff), "+s"(r.mask), "+s"(r.chunks), "+s"(r.chunks_small), "+s"(r.h[1]), "+s"(r.h[2]),
+                 : "+s"(r.rowoff), "+s"(r.mask), "+s"(r.chunks), "+s"(r.h[1]), "+s"(r.h[2]),
                    "+s"(r.h[3]), "+s"(r.h[4]), "+s"(r.h[5]), "+s"(r.h[6]), "+s"(r.h[7]),
                    "+s"(r.h[8]), "+s"(r.h[9]), "+s"(r.h[10]), "+s"(r.h[11]), "+s"(r.h[12]),
                    "+s"(r.h[13]), "+s"(r.h[14]), "+s"(r.h[15]));
@@ -277,7 +276,7 @@ __device__ __forceinline__ void relax_column(const ColRegs &cur, const float *pv
     constexpr bool STATIC = MASK != 0u;
     const unsigned mask = STATIC ? MASK : cur.mask;
     // window chunks (float4) that the present offsets read: elements t .. t+K-1
-    unsigned chunks = (K == STRIP_K) ? cur.chunks : cur.chunks_small;
+    unsigned chunks = cur.chunks;
     if (STATIC) {
         chunks = 0;
 #pragma unroll
@@ -343,12 +342,11 @@ __device__ __forceinline__ void relax_column(const ColRegs &cur, const float *pv
     }
 }
 
-// K cells per lane (strip length); the tile is always STRIP_TC cells wide, so a
-// workgroup has STRIP_TC / K waves.  K = 16: least overhead per relaxation (default).
-// K = 8: twice as many, half as long, units - used when there are few starts, where
-// the length of one workgroup's critical path, not throughput, sets the pass time.
+// K cells per lane (strip length); the tile is STRIP_TC cells wide, so a workgroup has
+// STRIP_TC / K waves.  (A K = 8 instance was measured: finer activity units, more
+// overhead per relaxation, same time to solution; only K = 16 is built.)
 template <int K>
-__global__ void __launch_bounds__(STRIP_TB *(STRIP_TC / K), (K == 16 ? 3 : 4))
+__global__ void __launch_bounds__(STRIP_TB *(STRIP_TC / K), 3)
 sweep_strip_kernel(DevLayout L, const float *__restrict__ v,
                    const StartDesc *__restrict__ starts, const int2 *__restrict__ work,
                    int *__restrict__ changed, const StripCol *__restrict__ cols,
@@ -524,7 +522,7 @@ int strip_tiles(const DevLayout &L)
     return L.n[0] * ((L.n[1] + STRIP_TB - 1) / STRIP_TB) * ((L.n[2] + STRIP_TC - 1) / STRIP_TC);
 }
 
-int strip_units(const DevLayout &L, int k) { return strip_tiles(L) * (STRIP_TC / k); }
+int strip_units(const DevLayout &L) { return strip_tiles(L) * STRIP_NS; }
 
 __global__ void __launch_bounds__(256)
 init_tile_flags_kernel(int *__restrict__ flags, int nunits, int start_unit)
@@ -536,8 +534,9 @@ init_tile_flags_kernel(int *__restrict__ flags, int nunits, int start_unit)
 }
 
 hipError_t launch_init_tile_flags(const DevLayout &L, const StartDesc &sd, bool all_active,
-                                  int k, hipStream_t st)
+                                  hipStream_t st)
 {
+    constexpr int k = STRIP_K;
     const int btiles = (L.n[1] + STRIP_TB - 1) / STRIP_TB;
     const int ctiles = (L.n[2] + STRIP_TC - 1) / STRIP_TC;
     const int cstrips = ctiles * (STRIP_TC / k);
@@ -576,13 +575,12 @@ static hipError_t launch_strip_k(const DevLayout &L, const float *v, const Start
 }
 
 hipError_t launch_sweep_strip(const DevLayout &L, const float *v, const StartDesc *starts,
-                              const int2 *work, long long nblocks, int k, int *changed,
+                              const int2 *work, long long nblocks, int *changed,
                               const StripCol *cols, const StripPlan &plan, int parity,
                               hipStream_t st)
 {
     if (nblocks <= 0) return hipSuccess;
     if (nblocks > 0x7fffffffLL) return hipErrorInvalidValue;
-    if (k == 8) return launch_strip_k<8>(L, v, starts, work, nblocks, changed, cols, plan, parity, st);
     return launch_strip_k<STRIP_K>(L, v, starts, work, nblocks, changed, cols, plan, parity, st);
 }
 
@@ -597,8 +595,9 @@ __global__ void __launch_bounds__(64)
 sweep_special_kernel(DevLayout L, const float *__restrict__ v,
                      const StartDesc *__restrict__ starts, const int *__restrict__ active,
                      int *__restrict__ changed, const CellEntry *__restrict__ entries,
-                     int nentries, int max_box_cells, int parity, int k)
+                     int nentries, int max_box_cells, int parity)
 {
+    constexpr int k = STRIP_K;
     const int s = active[blockIdx.x / max_box_cells];
     int cell = blockIdx.x % max_box_cells;
     const StartDesc sd = starts[s];
@@ -642,11 +641,11 @@ sweep_special_kernel(DevLayout L, const float *__restrict__ v,
 hipError_t launch_sweep_special(const DevLayout &L, const float *v, const StartDesc *starts,
                                 const int *active, int nactive, int *changed,
                                 const CellEntry *entries, int nentries, int max_box_cells,
-                                int parity, int k, hipStream_t st)
+                                int parity, hipStream_t st)
 {
     if (nactive <= 0 || max_box_cells <= 0) return hipSuccess;
     hipLaunchKernelGGL(sweep_special_kernel, dim3((unsigned)(nactive * max_box_cells)), dim3(64), 0,
-                       st, L, v, starts, active, changed, entries, nentries, max_box_cells, parity, k);
+                       st, L, v, starts, active, changed, entries, nentries, max_box_cells, parity);
     return hipGetLastError();
 }
 
