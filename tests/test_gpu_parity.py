@@ -77,6 +77,28 @@ def test_batch_of_starts_equals_single_solves(P, golden24):
         assert_bit_equal(tt, golden24.z[f"tt_{k}"], k)
 
 
+def test_host_solve_in_memory_sized_batches(P, golden24):
+    """ttsweep_solve splits the starts into batches that fit the device (forced here to
+    3 + 1); results and accumulated counters are those of the single-batch solve."""
+    offs = golden24.star("818")
+    fs = P.inputs.make_fs(offs)
+    keys = ["818_mid", "818_corner", "818_deadin", "818_deadout"]
+    starts = np.array([golden24.z[f"start_{k}"] for k in keys], dtype=np.int32)
+    with P.TravelTimeSolver(golden24.v.shape, fs) as sol:
+        sol.set_option(P.OPT_MAX_BATCH, 3)
+        sol.set_velocity(golden24.v)
+        tts = []
+        for st in starts:
+            tt = np.full(golden24.v.shape, np.inf, dtype=np.float32)
+            tt[tuple(st)] = 0
+            tts.append(tt)
+        assert sol.solve(starts, tts) == 1
+        st = sol.stats()
+    assert st["nstart"] == 4 and st["sweeps_total"] >= 8
+    for k, tt in zip(keys, tts):
+        assert_bit_equal(tt, golden24.z[f"tt_{k}"], k)
+
+
 def test_resume_and_idempotence(P, golden24, oracle):
     """The solve takes the box as its initial state: starting from the reference's
     state after ONE pass reaches the same fixed point, and solving a converged box

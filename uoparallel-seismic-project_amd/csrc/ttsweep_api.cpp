@@ -103,6 +103,7 @@ struct ttsweep_ctx {
     bool timing = false;
     long long max_sweeps = 100000;
     int batch_sweeps = 1;
+    int max_batch = 0;                      // cap on starts per ttsweep_solve batch (0: by memory)
 
     hipEvent_t ev_solve0 = nullptr, ev_solve1 = nullptr;
     hipEvent_t ev_flags[PASS_SLOTS] = {nullptr, nullptr, nullptr};     // "changed" words of a pass are on the host
@@ -590,6 +591,10 @@ int ttsweep_set_option(ttsweep_ctx *ctx, int key, long long value)
         if (value <= 0 || value > 1024) return set_error("batch sweeps out of range");
         ctx->batch_sweeps = (int)value;
         return 0;
+    case TTSWEEP_OPT_MAX_BATCH:
+        if (value < 0) return set_error("max batch must be >= 0");
+        ctx->max_batch = (int)value;
+        return 0;
     default: return set_error("unknown option %d", key);
     }
 }
@@ -781,27 +786,60 @@ int ttsweep_solve(ttsweep_ctx *ctx, int nstart, const ttsweep_start *starts,
     if (ctx_bind(ctx)) return -1;
     if (nstart == 0) return 0;
     const size_t cells = (size_t)ctx->nx * ctx->ny * ctx->nz;
-    float *stage = nullptr;
-    HIPCHK(hipMalloc((void **)&stage, (size_t)nstart * cells * sizeof(float)));
-    std::vector<float *> ptrs(nstart);
-    int rc = 0;
-    for (int s = 0; s < nstart && rc == 0; s++) {
-        ptrs[s] = stage + (size_t)s * cells;
-        hipError_t e = hipMemcpy(ptrs[s], tt_host[s], cells * sizeof(float), hipMemcpyHostToDevice);
-        if (e != hipSuccess) rc = set_error("travel-time upload failed: %s", hipGetErrorString(e));
-    }
-    if (rc == 0) rc = ttsweep_solve_device(ctx, nstart, starts, ptrs.data(), 0);
-    if (rc >= 0) {
-        for (int s = 0; s < nstart; s++) {
-            hipError_t e = hipMemcpy(tt_host[s], ptrs[s], cells * sizeof(float), hipMemcpyDeviceToHost);
-            if (e != hipSuccess) {
-                rc = set_error("travel-time download failed: %s", hipGetErrorString(e));
-                break;
+
+    // Starts are independent: solve them in batches that fit the device memory
+    // (per start: one staging box in the caller's layout + one padded volume).
+    size_t free_b = 0, total_b = 0;
+    HIPCHK(hipMemGetInfo(&free_b, &total_b));
+    if (ctx->d_T) free_b += (size_t)ctx->capacity_starts * ctx->L.cells * sizeof(float);   // reusable pool
+    const size_t per_start = (cells + (size_t)ctx->L.cells) * sizeof(float);
+    int batch = (int)std::min<size_t>((size_t)nstart, (size_t)(0.85 * (double)free_b) / per_start);
+    if (batch < 1) return set_error("not enough device memory for one travel-time volume");
+    if (ctx->max_batch > 0) batch = std::min(batch, ctx->max_batch);
+
+    ttsweep_stats total{};
+    int any = 0;
+    for (int first = 0; first < nstart; first += batch) {
+        const int n = std::min(batch, nstart - first);
+        float *stage = nullptr;
+        HIPCHK(hipMalloc((void **)&stage, (size_t)n * cells * sizeof(float)));
+        std::vector<float *> ptrs(n);
+        int rc = 0;
+        for (int s = 0; s < n && rc == 0; s++) {
+            ptrs[s] = stage + (size_t)s * cells;
+            hipError_t e = hipMemcpy(ptrs[s], tt_host[first + s], cells * sizeof(float),
+                                     hipMemcpyHostToDevice);
+            if (e != hipSuccess) rc = set_error("travel-time upload failed: %s", hipGetErrorString(e));
+        }
+        if (rc == 0) rc = ttsweep_solve_device(ctx, n, starts + first, ptrs.data(), 0);
+        if (rc >= 0) {
+            for (int s = 0; s < n; s++) {
+                hipError_t e = hipMemcpy(tt_host[first + s], ptrs[s], cells * sizeof(float),
+                                         hipMemcpyDeviceToHost);
+                if (e != hipSuccess) {
+                    rc = set_error("travel-time download failed: %s", hipGetErrorString(e));
+                    break;
+                }
             }
         }
+        (void)hipFree(stage);
+        if (rc < 0) return rc;
+        any |= rc;
+        // accumulate the per-batch counters into one report
+        const ttsweep_stats &b = ctx->stats;
+        total.nstart += b.nstart;
+        total.sweeps_max = std::max(total.sweeps_max, b.sweeps_max);
+        total.sweeps_total += b.sweeps_total;
+        total.cells_relaxed += b.cells_relaxed;
+        total.cells = b.cells;
+        total.relaxations_per_sweep = b.relaxations_per_sweep;
+        total.launches += b.launches;
+        total.sweep_kernel_ms += b.sweep_kernel_ms;
+        total.solve_ms += b.solve_ms;
+        total.kernel_variant = b.kernel_variant;
     }
-    (void)hipFree(stage);
-    return rc;
+    ctx->stats = total;
+    return any;
 }
 
 int ttsweep_get_stats(const ttsweep_ctx *ctx, ttsweep_stats *out)
