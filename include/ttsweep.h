@@ -125,6 +125,16 @@ int ttsweep_solve_device(ttsweep_ctx *ctx, int nstart, const ttsweep_start *star
 
 int ttsweep_get_stats(const ttsweep_ctx *ctx, ttsweep_stats *out);
 
+/* On-device fixed-point check in the spirit of testconvergence
+ * (old/wavefront-openmp/wave-multistart.c:300-347) on serial_new's edge set: counts
+ * the (cell, offset) pairs through which one more reference sweep would still store
+ * (serial_new/...:219-249, evaluated without modifying the box) and the cells still at
+ * INFINITY.  Both are 0 for a converged box.  tt_dev: device memory, FLOATBOX layout.
+ * For grids where no CPU oracle run is feasible (one reference sweep of 1024x1024x512
+ * takes ~40 min).  Returns 0 on success, < 0 on error. */
+int ttsweep_validate_device(ttsweep_ctx *ctx, const ttsweep_start *start, const float *tt_dev,
+                            long long *open_edges, long long *cells_infinite);
+
 /* Multi-GPU form of ttsweep_solve for a host program: the start points are
  * independent (serial_new/...:158-162; mpi/backup.c:351-363 runs one start per
  * rank), so start s is solved on devices[s % ndev]; every device gets its own

@@ -263,6 +263,27 @@ def sampled_open_edges(v, tt, offs, start, nsample, seed):
     return open_edges
 
 
+def test_device_validator_matches_oracle_validator(P, golden24, oracle):
+    """ttsweep_validate_device counts exactly what the oracle's validator counts: 0 on
+    converged boxes, the same positive numbers on the reference's one- and two-pass
+    states (818-FS and the non-symmetric star)."""
+    import torch
+    dev = torch.device("cuda:0")
+    for sname in ("818", "nonsym"):
+        offs = golden24.star(sname)
+        m = golden24.meta[f"pass_{sname}"]
+        start = m["start"]
+        ofs = oracle.make_star(offs)
+        conv, _, _ = oracle.converge(golden24.v, ofs, start)
+        with P.TravelTimeSolver(golden24.v.shape, P.inputs.make_fs(offs)) as sol:
+            sol.set_velocity(golden24.v)
+            for tt in (conv, golden24.z[f"pass1_{sname}"], golden24.z[f"pass2_{sname}"]):
+                want = oracle.validate(golden24.v, tt, ofs, start)
+                got = sol.validate_device(start, torch.from_numpy(np.ascontiguousarray(tt)).to(dev))
+                assert got == want, (sname, got, want)
+            assert sol.validate_device(start, torch.from_numpy(conv).to(dev)) == (0, 0)
+
+
 def test_sampled_checker_detects_unconverged_state(P, golden24, oracle):
     """The sampled validator itself: 0 on a converged fixture, > 0 one pass earlier."""
     offs = golden24.star("818")
@@ -276,8 +297,8 @@ def test_sampled_checker_detects_unconverged_state(P, golden24, oracle):
 def test_512_grid_properties(P):
     """818-FS on 512x512x256: the STRIP and CELL kernels (independent implementations,
     different layouts and schedules) agree bit for bit, no INFINITY is left, the start
-    stays 0, a second solve changes nothing, and the reference's store conditions
-    hold at 20000 sampled cells."""
+    stays 0, a second solve changes nothing, and the reference's store conditions hold
+    at every cell (device validator) and at 20000 sampled cells (numpy, independent)."""
     import torch
     shape = (512, 512, 256)
     dev = torch.device("cuda:0")
@@ -294,6 +315,7 @@ def test_512_grid_properties(P):
             assert sol.solve_device(starts, tt, init=True) == 1
             if kernel == 2:
                 assert sol.solve_device(starts, tt, init=False) == 0
+                assert sol.validate_device(starts[0], tt[0]) == (0, 0)      # every cell, on the device
             out[kernel] = tt[0].cpu().numpy()
     assert np.array_equal(out[1].view(np.uint32), out[2].view(np.uint32))
     tt = out[2]

@@ -31,7 +31,8 @@ def test_host_program_end_to_end(exe, pkg, oracle, tmp_path):
     (tmp_path / "starts.txt").write_text(
         f"{len(starts)}\n" + "".join(f"{i} {j} {k}\n" for i, j, k in starts))
     star = pkg.inputs.star_path("818")
-    r = subprocess.run([exe, "model.vbox", star, "starts.txt"], cwd=tmp_path,
+    env = dict(os.environ, TTSWEEP_BINARY_OUTPUT="tt-")
+    r = subprocess.run([exe, "model.vbox", star, "starts.txt"], cwd=tmp_path, env=env,
                        capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr
     out = r.stdout
@@ -58,6 +59,9 @@ def test_host_program_end_to_end(exe, pkg, oracle, tmp_path):
         got = np.array([float(l.split(": ")[1].split()[0]) for l in lines[base + 1: base + 1 + n]])
         exp = np.array([float("%f" % x) for x in want.reshape(-1)])
         assert np.array_equal(got, exp), s
+        # the compact binary volume holds the exact floats
+        origin, box = pkg.inputs.read_vbox(str(tmp_path / f"tt-{s}.vbox"))
+        assert origin == (1, 1, 1) and np.array_equal(box.view(np.uint32), want.view(np.uint32))
 
 
 def test_host_program_rejects_bad_input(exe, tmp_path):

@@ -73,6 +73,8 @@ struct ttsweep_ctx {
     bool have_v = false;
     CellEntry *d_cell_entries = nullptr;
     int n_cell_entries = 0;
+    FwdEntry *d_fwd_entries = nullptr;      // forward star entries (validator)
+    int n_fwd_entries = 0;
 
     // STRIP kernel: (da, db) columns of the star, dead-edge boxes
     StripCol *d_strip_cols = nullptr;
@@ -283,6 +285,23 @@ static int upload_star(ttsweep_ctx *ctx)
     // order by address so consecutive entries touch neighbouring cache lines
     std::sort(ce.begin(), ce.end(),
               [](const CellEntry &x, const CellEntry &y) { return x.delta < y.delta; });
+    {   // forward entries in device axes for the validator: exactly the entries whose
+        // edge is centred on the cell (PULL_FWD), i.e. the reference's (cell, l) pairs
+        std::vector<FwdEntry> fe;
+        for (const auto &q : ctx->pull) {
+            if (!(q.flags & PULL_FWD)) continue;
+            const int u[3] = {q.di, q.dj, q.dk};
+            fe.push_back(FwdEntry{u[L.perm[0]], u[L.perm[1]], u[L.perm[2]], q.h});
+        }
+        if (ctx->d_fwd_entries) HIPCHK(hipFree(ctx->d_fwd_entries));
+        ctx->d_fwd_entries = nullptr;
+        ctx->n_fwd_entries = (int)fe.size();
+        if (!fe.empty()) {
+            HIPCHK(hipMalloc((void **)&ctx->d_fwd_entries, fe.size() * sizeof(FwdEntry)));
+            HIPCHK(hipMemcpy(ctx->d_fwd_entries, fe.data(), fe.size() * sizeof(FwdEntry),
+                             hipMemcpyHostToDevice));
+        }
+    }
     if (ctx->d_cell_entries) HIPCHK(hipFree(ctx->d_cell_entries));
     ctx->d_cell_entries = nullptr;
     ctx->n_cell_entries = (int)ce.size();
@@ -534,6 +553,7 @@ void ttsweep_destroy(ttsweep_ctx *ctx)
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     (void)hipFree(ctx->d_v);
     (void)hipFree(ctx->d_cell_entries);
+    (void)hipFree(ctx->d_fwd_entries);
     (void)hipFree(ctx->d_strip_cols);
     (void)hipFree(ctx->d_T);
     (void)hipFree(ctx->d_starts);
@@ -840,6 +860,32 @@ int ttsweep_solve(ttsweep_ctx *ctx, int nstart, const ttsweep_start *starts,
     }
     ctx->stats = total;
     return any;
+}
+
+int ttsweep_validate_device(ttsweep_ctx *ctx, const ttsweep_start *start, const float *tt_dev,
+                            long long *open_edges, long long *cells_infinite)
+{
+    if (!ctx || !start || !tt_dev) return set_error("null argument");
+    if (!ctx->have_v) return set_error("velocity not set");
+    if (start->i < 0 || start->i >= ctx->nx || start->j < 0 || start->j >= ctx->ny || start->k < 0
+        || start->k >= ctx->nz)
+        return set_error("start outside the grid");
+    if (ctx_bind(ctx)) return -1;
+    if (ensure_capacity(ctx, 1)) return -1;
+    const DevLayout &L = ctx->L;
+    const int u[3] = {start->i, start->j, start->k};
+    const long long sidx = dev_index(L, u[L.perm[0]], u[L.perm[1]], u[L.perm[2]]);
+    unsigned long long *d_counts = ctx->d_work;     // two words of the per-solve counters
+    HIPCHK(hipMemsetAsync(d_counts, 0, 2 * sizeof(unsigned long long), ctx->stream));
+    HIPCHK(launch_pack(L, tt_dev, ctx->d_T, INFINITY, ctx->stream));
+    HIPCHK(launch_validate(L, ctx->d_v, ctx->d_T, sidx, ctx->d_fwd_entries, ctx->n_fwd_entries,
+                           d_counts, ctx->stream));
+    unsigned long long h[2] = {0, 0};
+    HIPCHK(hipMemcpyAsync(h, d_counts, sizeof h, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    if (open_edges) *open_edges = (long long)h[0];
+    if (cells_infinite) *cells_infinite = (long long)h[1];
+    return 0;
 }
 
 int ttsweep_get_stats(const ttsweep_ctx *ctx, ttsweep_stats *out)

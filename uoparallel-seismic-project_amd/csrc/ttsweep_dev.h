@@ -45,6 +45,12 @@ struct CellEntry {
     int pad_;
 };
 
+// One forward star entry in device axes, for the validator kernel.
+struct FwdEntry {
+    int da, db, dc;
+    float h;
+};
+
 // Per-start device record.
 struct StartDesc {
     float *T;               // padded travel-time volume of this start

@@ -25,6 +25,12 @@ hipError_t launch_sweep_cell(const DevLayout &L, const float *v, const StartDesc
                              const int *active, int nactive, int *changed,
                              const CellEntry *entries, int nentries, hipStream_t st);
 
+// ---- validator: counts[0] += (cell, forward entry) pairs a reference sweep would still
+// store through, counts[1] += cells still at +INFINITY (T is one padded volume)
+hipError_t launch_validate(const DevLayout &L, const float *v, const float *T, long long sidx,
+                           const FwdEntry *entries, int nentries, unsigned long long *counts,
+                           hipStream_t st);
+
 // ---- sweep, variant STRIP --------------------------------------------------
 // Same contract as launch_sweep_cell, but cells inside a start's dead-edge box
 // (StartDesc::box_*) are left untouched; launch_sweep_special relaxes exactly

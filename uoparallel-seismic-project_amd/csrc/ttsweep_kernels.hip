@@ -182,6 +182,72 @@ hipError_t launch_sweep_cell(const DevLayout &L, const float *v, const StartDesc
 
 
 // ===========================================================================
+// validator: the reference's store conditions, read-only
+// ===========================================================================
+// For every interior centre cell c != start and every forward entry (offset e, l in
+// [starstart, starstop)) with c + e inside the grid: would serial_new/...:225-249 store?
+//   exactly one of T[c], T[o] infinite, or delay + T[o] < T[c], or delay + T[c] < T[o].
+
+__global__ void __launch_bounds__(CELL_BX *CELL_BY)
+validate_kernel(DevLayout L, const float *__restrict__ v, const float *__restrict__ T,
+                long long sidx, const FwdEntry *__restrict__ entries, int nentries,
+                unsigned long long *__restrict__ counts, int cblocks, int bblocks)
+{
+    unsigned bid = blockIdx.x;
+    const int cb = bid % cblocks; bid /= cblocks;
+    const int bb = bid % bblocks; bid /= bblocks;
+    const int a = bid;
+    const int c = cb * CELL_BX + threadIdx.x;
+    const int b = bb * CELL_BY + threadIdx.y;
+    unsigned open = 0, inf = 0;
+    if (c < L.n[2] && b < L.n[1]) {
+        const long long ci = dev_index(L, a, b, c);
+        const float vc = v[ci], tc = T[ci];
+        inf = (tc == __builtin_inff());
+        if (ci != sidx) {
+            for (int e = 0; e < nentries; e++) {
+                const FwdEntry en = entries[e];
+                const int oa = a + en.da, ob = b + en.db, oc = c + en.dc;
+                if ((unsigned)oa >= (unsigned)L.n[0] || (unsigned)ob >= (unsigned)L.n[1]
+                    || (unsigned)oc >= (unsigned)L.n[2])
+                    continue;
+                const long long oi = dev_index(L, oa, ob, oc);
+                const float to = T[oi];
+                const float sum = vc + v[oi];
+                const float delay = en.h * sum;
+                const bool tinf = tc == __builtin_inff(), oinf = to == __builtin_inff();
+                if (tinf && oinf) continue;
+                if (tinf != oinf || delay + to < tc || delay + tc < to) open++;
+            }
+        }
+    }
+    // wave-level sums, one atomic pair per wave
+#pragma unroll
+    for (int w = 32; w >= 1; w >>= 1) {
+        open += __shfl_xor(open, w);
+        inf += __shfl_xor(inf, w);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        if (open) atomicAdd(&counts[0], (unsigned long long)open);
+        if (inf) atomicAdd(&counts[1], (unsigned long long)inf);
+    }
+}
+
+hipError_t launch_validate(const DevLayout &L, const float *v, const float *T, long long sidx,
+                           const FwdEntry *entries, int nentries, unsigned long long *counts,
+                           hipStream_t st)
+{
+    const int cblocks = (L.n[2] + CELL_BX - 1) / CELL_BX;
+    const int bblocks = (L.n[1] + CELL_BY - 1) / CELL_BY;
+    const long long nblocks = (long long)L.n[0] * bblocks * cblocks;
+    if (nblocks <= 0) return hipSuccess;
+    if (nblocks > 0x7fffffffLL) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(validate_kernel, dim3((unsigned)nblocks), dim3(CELL_BX, CELL_BY), 0, st, L, v,
+                       T, sidx, entries, nentries, counts, cblocks, bblocks);
+    return hipGetLastError();
+}
+
+// ===========================================================================
 // sweep, variant STRIP: LDS-staged neighbour planes, register strips
 // ===========================================================================
 //

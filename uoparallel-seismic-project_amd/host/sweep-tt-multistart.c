@@ -27,7 +27,10 @@
  *
  * Environment: TTSWEEP_DEVICE=<n> selects the GPU (default 0); TTSWEEP_GPUS=<N>
  * shards the start points over GPUs 0..N-1 (ttsweep_solve_multi);
- * TTSWEEP_NO_OUTPUT=1 skips writing output.tt (2.96 M text lines per start).
+ * TTSWEEP_NO_OUTPUT=1 skips writing output.tt (2.96 M text lines per start);
+ * TTSWEEP_BINARY_OUTPUT=<prefix> additionally writes every travel-time volume as
+ * <prefix><s>.vbox (VBOX format, same origin as the velocity model): the compact
+ * form for the large grids, readable with vbfileloadbinary.
  */
 #include "velocityboxfiler.h"
 #include "ttsweep.h"
@@ -176,6 +179,22 @@ int main(int argc, char *argv[])
         }
         for (s = 0; s < numstart; s++) anychange += changed[s];
         printf("sweep %d finished: anychange = %d\n", numsweeps, anychange);
+    }
+
+    /* compact binary result volumes (optional) */
+    if (getenv("TTSWEEP_BINARY_OUTPUT") != NULL) {
+        for (s = 0; s < numstart; s++) {
+            char name[1024];
+            struct VELOCITYBOX out;
+            out.min = vbox.min;
+            out.max = vbox.max;
+            out.box = ttboxes[s];
+            snprintf(name, sizeof name, "%s%d.vbox", getenv("TTSWEEP_BINARY_OUTPUT"), s);
+            if (!vbfilestorebinary(name, out)) {
+                printf("Can not write travel time volume: %s\n", name);
+                exit(1);
+            }
+        }
     }
 
     /* print travel times */

@@ -141,6 +141,19 @@ class TravelTimeSolver:
         return _check(self._L.ttsweep_solve_device(self._ctx, len(arr), arr, ptrs, int(init)),
                       "ttsweep_solve_device")
 
+    def validate_device(self, start, tt):
+        """(open_edges, cells_infinite) of one box in HBM (torch tensor [nx,ny,nz]):
+        the reference's store conditions evaluated on the device; (0, 0) when converged."""
+        import torch
+        assert tt.is_cuda and tt.dtype == torch.float32 and tt.is_contiguous()
+        assert tuple(tt.shape) == self.shape
+        torch.cuda.current_stream(tt.device).synchronize()
+        st = Start(int(start[0]), int(start[1]), int(start[2]))
+        a, b = C.c_longlong(0), C.c_longlong(0)
+        _check(self._L.ttsweep_validate_device(self._ctx, C.byref(st), tt.data_ptr(), C.byref(a),
+                                               C.byref(b)), "ttsweep_validate_device")
+        return a.value, b.value
+
     def stats(self) -> dict:
         st = Stats()
         _check(self._L.ttsweep_get_stats(self._ctx, C.byref(st)), "ttsweep_get_stats")
