@@ -82,13 +82,19 @@ struct ttsweep_ctx {
     std::vector<std::array<int, 3>> special_offsets;   // device-axis offsets e: cell start - e owns a dead edge
     bool start_is_special = false;
     int max_box_cells = 0;                  // of the current solve
-    int2 *d_worklist = nullptr;             // STRIP: block -> (start, tile)
-    size_t worklist_cap = 0;
-    long long worklist_len = 0;
-    std::vector<std::vector<int>> tile_order;   // per start: tile ids, nearest to the start first
+    // STRIP: block -> (start, tile); shape 0: a workgroup is a tile of STRIP_NS strips,
+    // shape 1 (COOP): a workgroup is one strip-unit
+    int2 *d_worklist[2] = {nullptr, nullptr};
+    size_t worklist_cap[2] = {0, 0};
+    long long worklist_len[2] = {0, 0};
+    std::vector<std::vector<int>> tile_order[2];    // per start: tile ids, nearest to the start first
+    long long coop_below = 3000;            // units relaxed in a pass below which the next
+                                            // pass uses one-unit workgroups
     int *d_tile_flags = nullptr;            // capacity_starts x 2 x tiles
     unsigned long long *d_work = nullptr;   // capacity_starts
     unsigned long long *h_work = nullptr;   // pinned
+    unsigned long long *h_units = nullptr;  // pinned, per pass slot
+    size_t h_units_cap = 0;
     int pass_index = 0;
 
     // per-solve pools (grown on demand, reused between solves)
@@ -340,8 +346,8 @@ static int ensure_capacity(ttsweep_ctx *ctx, int nstart)
     HIPCHK(hipHostMalloc((void **)&ctx->h_changed, PASS_SLOTS * nstart * sizeof(int)));
     HIPCHK(hipMalloc((void **)&ctx->d_tile_flags,
                      (size_t)nstart * 2 * std::max(strip_units(ctx->L), 1) * sizeof(int)));
-    HIPCHK(hipMalloc((void **)&ctx->d_work, 2 * nstart * sizeof(unsigned long long)));
-    HIPCHK(hipHostMalloc((void **)&ctx->h_work, 2 * nstart * sizeof(unsigned long long)));
+    HIPCHK(hipMalloc((void **)&ctx->d_work, 3 * nstart * sizeof(unsigned long long)));
+    HIPCHK(hipHostMalloc((void **)&ctx->h_work, 3 * nstart * sizeof(unsigned long long)));
     ctx->capacity_starts = nstart;
     return 0;
 }
@@ -366,9 +372,9 @@ static int timed_event(ttsweep_ctx *ctx, hipEvent_t *out)
 // tile usually runs after the tiles between it and the start have finished their
 // update of this pass: fresh travel times then cross several tiles in ONE pass
 // instead of one tile per pass.  Correctness never depends on this order.
-static int build_worklist(ttsweep_ctx *ctx, int nactive)
+static int build_worklist_shape(ttsweep_ctx *ctx, int nactive, int shape)
 {
-    const int ntiles = strip_tiles(ctx->L);
+    const int ntiles = shape == 0 ? strip_tiles(ctx->L) : strip_units(ctx->L);
     constexpr int NX = 8;
     std::vector<std::vector<int2>> per_xcd(NX);
     if (nactive >= NX) {
@@ -377,7 +383,7 @@ static int build_worklist(ttsweep_ctx *ctx, int nactive)
             for (int k = 0; k < ntiles; k++)
                 for (int a = x; a < nactive; a += NX) {
                     const int s = ctx->h_active[a];
-                    per_xcd[x].push_back(make_int2(s, ctx->tile_order[s][k]));
+                    per_xcd[x].push_back(make_int2(s, ctx->tile_order[shape][s][k]));
                 }
     } else {
         // start a owns XCDs a, a+nactive, ...; deal its tiles over them
@@ -386,7 +392,7 @@ static int build_worklist(ttsweep_ctx *ctx, int nactive)
             std::vector<int> mine;
             for (int x = a; x < NX; x += nactive) mine.push_back(x);
             for (int k = 0; k < ntiles; k++)
-                per_xcd[mine[k % mine.size()]].push_back(make_int2(s, ctx->tile_order[s][k]));
+                per_xcd[mine[k % mine.size()]].push_back(make_int2(s, ctx->tile_order[shape][s][k]));
         }
     }
     size_t longest = 0;
@@ -394,31 +400,37 @@ static int build_worklist(ttsweep_ctx *ctx, int nactive)
     std::vector<int2> flat(longest * NX, make_int2(0, -1));
     for (int x = 0; x < NX; x++)
         for (size_t j = 0; j < per_xcd[x].size(); j++) flat[j * NX + x] = per_xcd[x][j];
-    if (flat.size() > ctx->worklist_cap) {
-        if (ctx->d_worklist) HIPCHK(hipFree(ctx->d_worklist));
-        ctx->d_worklist = nullptr;
-        HIPCHK(hipMalloc((void **)&ctx->d_worklist, flat.size() * sizeof(int2)));
-        ctx->worklist_cap = flat.size();
+    if (flat.size() > ctx->worklist_cap[shape]) {
+        if (ctx->d_worklist[shape]) HIPCHK(hipFree(ctx->d_worklist[shape]));
+        ctx->d_worklist[shape] = nullptr;
+        HIPCHK(hipMalloc((void **)&ctx->d_worklist[shape], flat.size() * sizeof(int2)));
+        ctx->worklist_cap[shape] = flat.size();
     }
-    HIPCHK(hipMemcpyAsync(ctx->d_worklist, flat.data(), flat.size() * sizeof(int2),
+    HIPCHK(hipMemcpyAsync(ctx->d_worklist[shape], flat.data(), flat.size() * sizeof(int2),
                           hipMemcpyHostToDevice, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));      // `flat` is a stack-lifetime buffer
-    ctx->worklist_len = (long long)flat.size();
+    ctx->worklist_len[shape] = (long long)flat.size();
     return 0;
 }
 
+static int build_worklist(ttsweep_ctx *ctx, int nactive)
+{
+    return (build_worklist_shape(ctx, nactive, 0) || build_worklist_shape(ctx, nactive, 1)) ? -1 : 0;
+}
+
 // Tiles of one start ordered by distance (tile centre to start point).
-static void order_tiles(const ttsweep_ctx *ctx, const StartDesc &sd, std::vector<int> &order)
+static void order_tiles(const ttsweep_ctx *ctx, const StartDesc &sd, int shape, std::vector<int> &order)
 {
     const DevLayout &L = ctx->L;
     const int btiles = (L.n[1] + STRIP_TB - 1) / STRIP_TB;
-    const int ctiles = (L.n[2] + STRIP_TC - 1) / STRIP_TC;
+    const int tc = shape == 0 ? STRIP_TC : STRIP_K;     // tile extent along c
+    const int ctiles = ((L.n[2] + STRIP_TC - 1) / STRIP_TC) * (STRIP_TC / tc);
     const int ntiles = L.n[0] * btiles * ctiles;
     std::vector<std::pair<long long, int>> key(ntiles);
     for (int t = 0; t < ntiles; t++) {
         const int ct = t % ctiles, bt = (t / ctiles) % btiles, a = t / (ctiles * btiles);
         const long long cb = std::min(bt * STRIP_TB + STRIP_TB / 2, L.n[1] - 1);
-        const long long cc = std::min(ct * STRIP_TC + STRIP_TC / 2, L.n[2] - 1);
+        const long long cc = std::min(ct * tc + tc / 2, L.n[2] - 1);
         const long long da = a - sd.sa, db = cb - sd.sb, dc = cc - sd.sc;
         static const int order_mode = getenv("TTSWEEP_ORDER") ? atoi(getenv("TTSWEEP_ORDER")) : 8;
         if (order_mode == 0) key[t] = {((long long)bt * ctiles + ct) * L.n[0] + a, t};   // plane fastest
@@ -435,14 +447,14 @@ static void order_tiles(const ttsweep_ctx *ctx, const StartDesc &sd, std::vector
 }
 
 // One full-grid pass for the active starts.
-static int launch_pass(ttsweep_ctx *ctx, int nactive, int *d_changed)
+static int launch_pass(ttsweep_ctx *ctx, int nactive, int *d_changed, int shape)
 {
     hipEvent_t e0, e1;
     if (ctx->timing && timed_event(ctx, &e0)) return -1;
     if (ctx->kernel == TTSWEEP_KERNEL_STRIP) {
-        HIPCHK(launch_sweep_strip(ctx->L, ctx->d_v, ctx->d_starts, ctx->d_worklist,
-                                  ctx->worklist_len, d_changed, ctx->d_strip_cols, ctx->plan,
-                                  ctx->pass_index & 1, ctx->stream));
+        HIPCHK(launch_sweep_strip(ctx->L, ctx->d_v, ctx->d_starts, ctx->d_worklist[shape],
+                                  ctx->worklist_len[shape], shape == 1, d_changed,
+                                  ctx->d_strip_cols, ctx->plan, ctx->pass_index & 1, ctx->stream));
         HIPCHK(launch_sweep_special(ctx->L, ctx->d_v, ctx->d_starts, ctx->d_active, nactive,
                                     d_changed, ctx->d_cell_entries, ctx->n_cell_entries,
                                     ctx->max_box_cells, ctx->pass_index & 1, ctx->stream));
@@ -560,9 +572,11 @@ void ttsweep_destroy(ttsweep_ctx *ctx)
     (void)hipFree(ctx->d_active);
     (void)hipFree(ctx->d_changed);
     (void)hipFree(ctx->d_tile_flags);
-    (void)hipFree(ctx->d_worklist);
+    (void)hipFree(ctx->d_worklist[0]);
+    (void)hipFree(ctx->d_worklist[1]);
     (void)hipFree(ctx->d_work);
     if (ctx->h_work) (void)hipHostFree(ctx->h_work);
+    if (ctx->h_units) (void)hipHostFree(ctx->h_units);
     if (ctx->h_starts) (void)hipHostFree(ctx->h_starts);
     if (ctx->h_active) (void)hipHostFree(ctx->h_active);
     if (ctx->h_changed) (void)hipHostFree(ctx->h_changed);
@@ -681,13 +695,15 @@ int ttsweep_solve_device(ttsweep_ctx *ctx, int nstart, const ttsweep_start *star
             ctx->max_box_cells = std::max<long long>(s == 0 ? 0 : ctx->max_box_cells, vol);
         }
         sd.tile_flags = ctx->d_tile_flags + (size_t)s * 2 * std::max(strip_units(L), 1);
-        sd.work = ctx->d_work + 2 * s;
+        sd.work = ctx->d_work + 3 * s;
         if (init) HIPCHK(launch_init_tt(L, sd.T, sd.sidx, ctx->stream));
         else HIPCHK(launch_pack(L, tt_dev[s], sd.T, INFINITY, ctx->stream));
         if (ctx->kernel == TTSWEEP_KERNEL_STRIP) {
             HIPCHK(launch_init_tile_flags(L, sd, /*all_active=*/!init, ctx->stream));
-            if ((int)ctx->tile_order.size() < nstart) ctx->tile_order.resize(nstart);
-            order_tiles(ctx, sd, ctx->tile_order[s]);
+            for (int shape = 0; shape < 2; shape++) {
+                if ((int)ctx->tile_order[shape].size() < nstart) ctx->tile_order[shape].resize(nstart);
+                order_tiles(ctx, sd, shape, ctx->tile_order[shape][s]);
+            }
         }
         ctx->h_active[s] = s;
     }
@@ -695,7 +711,7 @@ int ttsweep_solve_device(ttsweep_ctx *ctx, int nstart, const ttsweep_start *star
                           hipMemcpyHostToDevice, ctx->stream));
     HIPCHK(hipMemcpyAsync(ctx->d_active, ctx->h_active, nstart * sizeof(int),
                           hipMemcpyHostToDevice, ctx->stream));
-    HIPCHK(hipMemsetAsync(ctx->d_work, 0, 2 * nstart * sizeof(unsigned long long), ctx->stream));
+    HIPCHK(hipMemsetAsync(ctx->d_work, 0, 3 * nstart * sizeof(unsigned long long), ctx->stream));
     ctx->pass_index = 0;
     if (ctx->kernel == TTSWEEP_KERNEL_STRIP && build_worklist(ctx, nstart)) return -1;
 
@@ -708,6 +724,19 @@ int ttsweep_solve_device(ttsweep_ctx *ctx, int nstart, const ttsweep_start *star
     const bool trace = getenv("TTSWEEP_TRACE") != nullptr;
     unsigned long long trace_prev = 0, trace_prev_wg = 0;
     std::vector<int> snapshot[PASS_SLOTS];      // active starts of each pass in flight
+    // workgroup shape of the next pass: one-unit (COOP) workgroups while only a thin front is
+    // active, tiles of STRIP_NS units when the pass fills the machine.  The number of units
+    // relaxed per pass is read back with the "changed" words (so it lags one pass).
+    int shape = 1;                              // the first passes only touch the start's surroundings
+    unsigned long long units_prev = 0;
+    if (const char *env = getenv("TTSWEEP_COOP_BELOW")) ctx->coop_below = atoll(env);
+    if (ctx->h_units_cap < (size_t)PASS_SLOTS * 3 * nstart) {
+        if (ctx->h_units) HIPCHK(hipHostFree(ctx->h_units));
+        ctx->h_units = nullptr;
+        HIPCHK(hipHostMalloc((void **)&ctx->h_units, (size_t)PASS_SLOTS * 3 * nstart * sizeof(unsigned long long)));
+        ctx->h_units_cap = (size_t)PASS_SLOTS * 3 * nstart;
+    }
+    unsigned long long *h_units = ctx->h_units;
     int nactive = nstart, launched = 0, processed = 0;
     bool anychange_ever = false;
     auto t_pass = std::chrono::steady_clock::now();
@@ -716,9 +745,13 @@ int ttsweep_solve_device(ttsweep_ctx *ctx, int nstart, const ttsweep_start *star
             const int slot = launched % PASS_SLOTS;
             int *dch = ctx->d_changed + (size_t)slot * nstart;
             HIPCHK(hipMemsetAsync(dch, 0, nstart * sizeof(int), ctx->stream));
-            if (launch_pass(ctx, nactive, dch)) return -1;
+            if (launch_pass(ctx, nactive, dch, shape)) return -1;
             HIPCHK(hipMemcpyAsync(ctx->h_changed + (size_t)slot * nstart, dch, nstart * sizeof(int),
                                   hipMemcpyDeviceToHost, ctx->stream));
+            if (ctx->kernel == TTSWEEP_KERNEL_STRIP)        // units relaxed so far (shape choice)
+                HIPCHK(hipMemcpyAsync(h_units + (size_t)slot * 3 * nstart, ctx->d_work,
+                                      3 * nstart * sizeof(unsigned long long),
+                                      hipMemcpyDeviceToHost, ctx->stream));
             HIPCHK(hipEventRecord(ctx->ev_flags[slot], ctx->stream));
             snapshot[slot].assign(ctx->h_active, ctx->h_active + nactive);
             launched++;
@@ -728,20 +761,26 @@ int ttsweep_solve_device(ttsweep_ctx *ctx, int nstart, const ttsweep_start *star
         const int slot = processed % PASS_SLOTS;
         HIPCHK(hipEventSynchronize(ctx->ev_flags[slot]));
         const int *hch = ctx->h_changed + (size_t)slot * nstart;
+        if (ctx->kernel == TTSWEEP_KERNEL_STRIP) {
+            unsigned long long units = 0;
+            for (int s = 0; s < nstart; s++) units += h_units[(size_t)slot * 3 * nstart + 3 * s + 2];
+            shape = (long long)(units - units_prev) < ctx->coop_below ? 1 : 0;
+            units_prev = units;
+        }
         if (trace) {    // TTSWEEP_TRACE=1: per-pass activity on stderr (serialises the passes)
             HIPCHK(hipStreamSynchronize(ctx->stream));
-            HIPCHK(hipMemcpy(ctx->h_work, ctx->d_work, 2 * nstart * sizeof(unsigned long long),
+            HIPCHK(hipMemcpy(ctx->h_work, ctx->d_work, 3 * nstart * sizeof(unsigned long long),
                              hipMemcpyDeviceToHost));
             unsigned long long tot = 0, wgs = 0;
-            for (int s = 0; s < nstart; s++) { tot += ctx->h_work[2 * s]; wgs += ctx->h_work[2 * s + 1]; }
+            for (int s = 0; s < nstart; s++) { tot += ctx->h_work[3 * s]; wgs += ctx->h_work[3 * s + 1]; }
             const double us = std::chrono::duration<double, std::micro>(
                                   std::chrono::steady_clock::now() - t_pass).count();
             t_pass = std::chrono::steady_clock::now();
             fprintf(stderr, "ttsweep pass %d: %d active starts, %.3f full-sweep equivalents relaxed, "
-                    "%llu workgroups ran, %.0f us\n", processed + 1, (int)snapshot[slot].size(),
+                    "%llu workgroups ran, %.0f us, next shape %d\n", processed + 1, (int)snapshot[slot].size(),
                     (double)(tot - trace_prev) / (double)ctx->stats.cells
                         / (double)std::max<size_t>(ctx->pull.size(), 1),
-                    wgs - trace_prev_wg, us);
+                    wgs - trace_prev_wg, us, shape);
             trace_prev = tot;
             trace_prev_wg = wgs;
         }
@@ -775,7 +814,7 @@ int ttsweep_solve_device(ttsweep_ctx *ctx, int nstart, const ttsweep_start *star
 
     for (int s = 0; s < nstart; s++)
         HIPCHK(launch_unpack(L, ctx->h_starts[s].T, tt_dev[s], ctx->stream));
-    HIPCHK(hipMemcpyAsync(ctx->h_work, ctx->d_work, 2 * nstart * sizeof(unsigned long long),
+    HIPCHK(hipMemcpyAsync(ctx->h_work, ctx->d_work, 3 * nstart * sizeof(unsigned long long),
                           hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipEventRecord(ctx->ev_solve1, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
@@ -793,7 +832,7 @@ int ttsweep_solve_device(ttsweep_ctx *ctx, int nstart, const ttsweep_start *star
         // CELL kernel relaxes every cell in every pass; STRIP counts its active tiles
         // (STRIP counts cells x offsets actually relaxed; convert to whole-star cell relaxations)
         ctx->stats.cells_relaxed += ctx->kernel == TTSWEEP_KERNEL_STRIP
-            ? (long long)(ctx->h_work[2 * s] / std::max<size_t>(ctx->pull.size(), 1))
+            ? (long long)(ctx->h_work[3 * s] / std::max<size_t>(ctx->pull.size(), 1))
             : (long long)sweeps[s] * ctx->stats.cells;
     }
     return anychange_ever ? 1 : 0;
@@ -875,7 +914,7 @@ int ttsweep_validate_device(ttsweep_ctx *ctx, const ttsweep_start *start, const 
     const DevLayout &L = ctx->L;
     const int u[3] = {start->i, start->j, start->k};
     const long long sidx = dev_index(L, u[L.perm[0]], u[L.perm[1]], u[L.perm[2]]);
-    unsigned long long *d_counts = ctx->d_work;     // two words of the per-solve counters
+    unsigned long long *d_counts = ctx->d_work;     // first words of the per-solve counters
     HIPCHK(hipMemsetAsync(d_counts, 0, 2 * sizeof(unsigned long long), ctx->stream));
     HIPCHK(launch_pack(L, tt_dev, ctx->d_T, INFINITY, ctx->stream));
     HIPCHK(launch_validate(L, ctx->d_v, ctx->d_T, sidx, ctx->d_fwd_entries, ctx->n_fwd_entries,

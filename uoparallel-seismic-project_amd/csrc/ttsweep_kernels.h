@@ -39,13 +39,14 @@ hipError_t launch_validate(const DevLayout &L, const float *v, const float *T, l
 // Activity tracking: a tile is relaxed in pass k only if a tile it reads from
 // (itself, its 8 in-plane neighbours, over all plane offsets) improved in pass
 // k-1; `parity` = k & 1 selects which half of StartDesc::tile_flags is written.
-size_t strip_lds_bytes(const StripPlan &plan, int nb);
+size_t strip_lds_bytes(const StripPlan &plan, int nb, bool coop);
 int strip_tiles(const DevLayout &L);            // workgroup tiles per start
 int strip_units(const DevLayout &L);            // activity units (one per wave) per start
 // work[b] = (start index, tile id) of block b, tile id = (a*btiles + bt)*ctiles + ct,
-// or tile id < 0 for a padding entry.
+// or tile id < 0 for a padding entry.  coop: one unit per workgroup (tile id = unit id,
+// ctiles = strips along c), its waves sharing the star's columns - for sparse passes.
 hipError_t launch_sweep_strip(const DevLayout &L, const float *v, const StartDesc *starts,
-                              const int2 *work, long long nblocks, int *changed,
+                              const int2 *work, long long nblocks, bool coop, int *changed,
                               const StripCol *cols, const StripPlan &plan, int parity,
                               hipStream_t st);
 hipError_t launch_sweep_special(const DevLayout &L, const float *v, const StartDesc *starts,

@@ -408,10 +408,17 @@ __device__ __forceinline__ void relax_column(const ColRegs &cur, const float *pv
     }
 }
 
-// K cells per lane (strip length); the tile is STRIP_TC cells wide, so a workgroup has
-// STRIP_TC / K waves.  (A K = 8 instance was measured: finer activity units, more
-// overhead per relaxation, same time to solution; only K = 16 is built.)
-template <int K>
+// K cells per lane (strip length).  (A K = 8 instance was measured: finer activity units,
+// more overhead per relaxation, same time to solution; only K = 16 is built.)
+//
+// Two workgroup shapes share this body:
+//   COOP = false  workgroup = STRIP_TC / K strips of one tile, one wave per strip (unit).
+//                 Least staging per cell; the shape for passes that fill the machine.
+//   COOP = true   workgroup = ONE unit; its waves split the star's columns among
+//                 themselves and min-combine their partial results through LDS.  Four
+//                 times shorter critical path per unit; the shape for passes in which only
+//                 a thin front is active and the pass time is the time of one workgroup.
+template <int K, bool COOP>
 __global__ void __launch_bounds__(STRIP_TB *(STRIP_TC / K), 3)
 sweep_strip_kernel(DevLayout L, const float *__restrict__ v,
                    const StartDesc *__restrict__ starts, const int2 *__restrict__ work,
@@ -419,8 +426,11 @@ sweep_strip_kernel(DevLayout L, const float *__restrict__ v,
                    StripPlan plan, int btiles, int ctiles, int parity)
 {
     static_assert(STRIP_TC % K == 0 && K % 4 == 0, "strips must tile the workgroup tile");
-    constexpr int NS = STRIP_TC / K;            // waves (strips) per workgroup
+    constexpr int NS = STRIP_TC / K;            // waves per workgroup
     constexpr int NT = STRIP_TB * NS;
+    constexpr int TC = COOP ? K : STRIP_TC;     // tile extent along c
+    constexpr int PWV = TC + 2 * STRIP_CF;      // valid floats per slab row
+    constexpr int PW = PWV + (((PWV / 4) % 2 == 0) ? 4 : 0);   // row pitch, PW/4 odd
     extern __shared__ __attribute__((aligned(16))) float smem[];
 
     // Block -> (start, tile) through a host-built work list (see build_worklist in
@@ -436,10 +446,11 @@ sweep_strip_kernel(DevLayout L, const float *__restrict__ v,
     const int a = tile_id;
 
     const int lane = threadIdx.x;
-    const int strip = threadIdx.y;
-    const int tid = strip * STRIP_TB + lane;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.y);   // wave-uniform: keep it scalar
+    const int strip = COOP ? 0 : wave;          // which strip of the tile this wave owns
+    const int tid = wave * STRIP_TB + lane;
     const int b0 = bt * STRIP_TB;
-    const int c0 = ct * STRIP_TC;
+    const int c0 = ct * TC;
     const int rb = plan.rb;
     const int tb_eff = min(STRIP_TB, L.n[1]);       // lanes that can own a cell
     const int rows = tb_eff + 2 * rb;
@@ -453,9 +464,9 @@ sweep_strip_kernel(DevLayout L, const float *__restrict__ v,
     // offsets with plane offset da have to be relaxed in this pass only if a unit they
     // read from (plane a+da, +-1 lane tile, +-1 strip) improved in the previous pass:
     // everything else was already relaxed against unchanged values.
-    const int cstrips = ctiles * NS;
+    const int cstrips = COOP ? ctiles : ctiles * NS;
     const int nunits = L.n[0] * btiles * cstrips;
-    const int my_cs = ct * NS + strip;
+    const int my_cs = COOP ? ct : ct * NS + strip;
     const int my_unit = (a * btiles + bt) * cstrips + my_cs;
     int *__restrict__ cur_flags = sd.tile_flags + parity * nunits;
     unsigned my_planes = 0;     // bit ia: plane offset da = ia - ra is due for this wave
@@ -476,16 +487,16 @@ sweep_strip_kernel(DevLayout L, const float *__restrict__ v,
         for (int w = 32; w >= 1; w >>= 1) my_planes |= __shfl_xor(my_planes, w);
     }
     const bool wave_active = my_planes != 0;
-    const unsigned wg_planes = block_or_mask<NS>(my_planes, smem, strip, lane);
+    const unsigned wg_planes = COOP ? my_planes : block_or_mask<NS>(my_planes, smem, wave, lane);
     if (wg_planes == 0) {
-        if (lane == 0) cur_flags[my_unit] = 0;
+        if (lane == 0 && (!COOP || wave == 0)) cur_flags[my_unit] = 0;
         return;
     }
 
     if (tid == 0) atomicAdd(sd.work + 1, 1ull);     // workgroups that had to run (statistics)
 
     float *sv = smem + STRIP_LDS_HEAD;
-    float *sT = sv + rows * STRIP_PW;
+    float *sT = sv + rows * PW;
 
     // own cells: (a, b0 + lane, c0 + strip*K + q)
     const long long own = (long long)(a + L.lo[0]) * L.s0 + (long long)(b0 + lane_r + L.lo[1]) * L.s1
@@ -503,7 +514,7 @@ sweep_strip_kernel(DevLayout L, const float *__restrict__ v,
 #pragma unroll
     for (int p = 0; p < K / 2 - 1; p++) vco[p] = f32x2{vce[p].y, vce[p + 1].x};
 
-    constexpr int F4_PER_ROW = STRIP_PWV / 4;
+    constexpr int F4_PER_ROW = PWV / 4;
     const int nf4 = rows * F4_PER_ROW;
 
     for (int ia = 0; ia <= 2 * plan.ra; ia++) {
@@ -521,8 +532,8 @@ sweep_strip_kernel(DevLayout L, const float *__restrict__ v,
             const long long g = src + (long long)r * L.s1 + 4 * c4;
             const float4 xv = *reinterpret_cast<const float4 *>(v + g);
             const float4 xt = *reinterpret_cast<const float4 *>(T + g);
-            *reinterpret_cast<float4 *>(sv + r * STRIP_PW + 4 * c4) = xv;
-            *reinterpret_cast<float4 *>(sT + r * STRIP_PW + 4 * c4) = xt;
+            *reinterpret_cast<float4 *>(sv + r * PW + 4 * c4) = xv;
+            *reinterpret_cast<float4 *>(sT + r * PW + 4 * c4) = xt;
         }
         __syncthreads();
 
@@ -530,12 +541,15 @@ sweep_strip_kernel(DevLayout L, const float *__restrict__ v,
         // in SGPRs; the NEXT column's descriptor is requested before this column's
         // arithmetic so its scalar-load latency is hidden.
         if (!((my_planes >> ia) & 1u)) continue;    // this wave only helps staging
-        ColRegs cur = load_col(cols, cbeg);
-        for (int ci = cbeg; ci < cend; ci++) {
+        constexpr int CSTEP = COOP ? NS : 1;        // COOP: the waves take the columns in turn
+        const int cfirst = COOP ? cbeg + wave : cbeg;
+        if (cfirst >= cend) continue;
+        ColRegs cur = load_col(cols, cfirst);
+        for (int ci = cfirst; ci < cend; ci += CSTEP) {
             pin_col(cur);
-            const ColRegs nxt = load_col(cols, min(ci + 1, cend - 1));
-            const float *pv = sv + (lane_r + rb + cur.rowoff) * STRIP_PW + strip * K;
-            const float *pt = pv + rows * STRIP_PW;
+            const ColRegs nxt = load_col(cols, min(ci + CSTEP, cend - 1));
+            const float *pv = sv + (lane_r + rb + cur.rowoff) * PW + strip * K;
+            const float *pt = pv + rows * PW;
             // columns whose dc set is one of the shipped stars' get a straight-line
             // routine (compile-time set: no per-offset branches, only the window chunks
             // that set needs); any other set takes the generic bit-test routine
@@ -547,6 +561,20 @@ sweep_strip_kernel(DevLayout L, const float *__restrict__ v,
             }
             cur = nxt;
         }
+    }
+
+    if (COOP) {
+        // min-combine the waves' partial results: [wave][cell][lane] floats in LDS
+        float *comb = smem + STRIP_LDS_HEAD;
+        __syncthreads();                // the last slab is no longer read
+#pragma unroll
+        for (int q = 0; q < K; q++) comb[(wave * K + q) * STRIP_TB + lane] = acc[q];
+        __syncthreads();
+        if (wave != 0) return;
+#pragma unroll
+        for (int w = 1; w < NS; w++)
+#pragma unroll
+            for (int q = 0; q < K; q++) acc[q] = fminf(acc[q], comb[(w * K + q) * STRIP_TB + lane]);
     }
 
     // ---- epilogue: store improved cells that lie inside the grid and outside the
@@ -579,6 +607,7 @@ sweep_strip_kernel(DevLayout L, const float *__restrict__ v,
             for (int ia = 0; ia <= 2 * plan.ra; ia++)
                 if ((my_planes >> ia) & 1u) nent += plan.nent[ia];
             atomicAdd(sd.work, (unsigned long long)(wb * wc) * (unsigned long long)nent);
+            atomicAdd(sd.work + 2, 1ull);       // units relaxed (drives the choice of workgroup shape)
         }
     }
 }
@@ -589,6 +618,8 @@ int strip_tiles(const DevLayout &L)
 }
 
 int strip_units(const DevLayout &L) { return strip_tiles(L) * STRIP_NS; }
+
+static int strip_cstrips(const DevLayout &L) { return ((L.n[2] + STRIP_TC - 1) / STRIP_TC) * STRIP_NS; }
 
 __global__ void __launch_bounds__(256)
 init_tile_flags_kernel(int *__restrict__ flags, int nunits, int start_unit)
@@ -614,22 +645,25 @@ hipError_t launch_init_tile_flags(const DevLayout &L, const StartDesc &sd, bool 
     return hipGetLastError();
 }
 
-size_t strip_lds_bytes(const StripPlan &plan, int nb)
+size_t strip_lds_bytes(const StripPlan &plan, int nb, bool coop)
 {
-    return ((size_t)2 * (std::min(STRIP_TB, nb) + 2 * plan.rb) * STRIP_PW + STRIP_LDS_HEAD)
-         * sizeof(float);
+    const int pwv = (coop ? STRIP_K : STRIP_TC) + 2 * STRIP_CF;
+    const int pw = pwv + (((pwv / 4) % 2 == 0) ? 4 : 0);
+    size_t floats = (size_t)2 * (std::min(STRIP_TB, nb) + 2 * plan.rb) * pw;
+    if (coop) floats = std::max(floats, (size_t)STRIP_TC * STRIP_TB);      // combine buffer
+    return (floats + STRIP_LDS_HEAD) * sizeof(float);
 }
 
-template <int K>
+template <int K, bool COOP>
 static hipError_t launch_strip_k(const DevLayout &L, const float *v, const StartDesc *starts,
                                  const int2 *work, long long nblocks, int *changed,
                                  const StripCol *cols, const StripPlan &plan, int parity,
                                  hipStream_t st)
 {
     const int btiles = (L.n[1] + STRIP_TB - 1) / STRIP_TB;
-    const int ctiles = (L.n[2] + STRIP_TC - 1) / STRIP_TC;
-    auto kern = sweep_strip_kernel<K>;
-    const size_t lds = strip_lds_bytes(plan, L.n[1]);
+    const int ctiles = COOP ? strip_cstrips(L) : (L.n[2] + STRIP_TC - 1) / STRIP_TC;
+    auto kern = sweep_strip_kernel<K, COOP>;
+    const size_t lds = strip_lds_bytes(plan, L.n[1], COOP);
     if (lds > 48 * 1024) {      // above the default dynamic-LDS limit
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -641,13 +675,15 @@ static hipError_t launch_strip_k(const DevLayout &L, const float *v, const Start
 }
 
 hipError_t launch_sweep_strip(const DevLayout &L, const float *v, const StartDesc *starts,
-                              const int2 *work, long long nblocks, int *changed,
+                              const int2 *work, long long nblocks, bool coop, int *changed,
                               const StripCol *cols, const StripPlan &plan, int parity,
                               hipStream_t st)
 {
     if (nblocks <= 0) return hipSuccess;
     if (nblocks > 0x7fffffffLL) return hipErrorInvalidValue;
-    return launch_strip_k<STRIP_K>(L, v, starts, work, nblocks, changed, cols, plan, parity, st);
+    if (coop)
+        return launch_strip_k<STRIP_K, true>(L, v, starts, work, nblocks, changed, cols, plan, parity, st);
+    return launch_strip_k<STRIP_K, false>(L, v, starts, work, nblocks, changed, cols, plan, parity, st);
 }
 
 // ===========================================================================
