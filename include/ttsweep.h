@@ -73,8 +73,7 @@ typedef struct ttsweep_ctx ttsweep_ctx;
 #define TTSWEEP_OPT_TIMING        1   /* 1: time every sweep launch with HIP events */
 #define TTSWEEP_OPT_KERNEL        2   /* force a kernel variant (TTSWEEP_KERNEL_*) */
 #define TTSWEEP_OPT_MAX_SWEEPS    3   /* safety cap on passes per solve (default 100000) */
-#define TTSWEEP_OPT_BATCH_SWEEPS  4   /* (reserved) */
-#define TTSWEEP_OPT_MAX_BATCH     5   /* ttsweep_solve: at most this many starts per device
+#define TTSWEEP_OPT_MAX_BATCH     4   /* ttsweep_solve: at most this many starts per device
                                          batch (0 = as many as device memory holds) */
 
 #define TTSWEEP_KERNEL_AUTO       0

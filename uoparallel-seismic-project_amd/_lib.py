@@ -62,7 +62,7 @@ SYMBOLS = [
                                                      C.c_int, C.c_int]),
 ]
 
-OPT_TIMING, OPT_KERNEL, OPT_MAX_SWEEPS, OPT_BATCH_SWEEPS, OPT_MAX_BATCH = 1, 2, 3, 4, 5
+OPT_TIMING, OPT_KERNEL, OPT_MAX_SWEEPS, OPT_MAX_BATCH = 1, 2, 3, 4
 KERNEL_AUTO, KERNEL_CELL, KERNEL_STRIP = 0, 1, 2
 
 

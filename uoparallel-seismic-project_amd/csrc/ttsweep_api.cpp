@@ -67,7 +67,6 @@ struct ttsweep_ctx {
 
     DevLayout L{};
     int kernel = TTSWEEP_KERNEL_CELL;
-    int forced_kernel = TTSWEEP_KERNEL_AUTO;
 
     float *d_v = nullptr;                   // padded velocity
     bool have_v = false;
@@ -110,7 +109,6 @@ struct ttsweep_ctx {
     // options
     bool timing = false;
     long long max_sweeps = 100000;
-    int batch_sweeps = 1;
     int max_batch = 0;                      // cap on starts per ttsweep_solve batch (0: by memory)
 
     hipEvent_t ev_solve0 = nullptr, ev_solve1 = nullptr;
@@ -431,15 +429,13 @@ static void order_tiles(const ttsweep_ctx *ctx, const StartDesc &sd, int shape, 
         const int ct = t % ctiles, bt = (t / ctiles) % btiles, a = t / (ctiles * btiles);
         const long long cb = std::min(bt * STRIP_TB + STRIP_TB / 2, L.n[1] - 1);
         const long long cc = std::min(ct * tc + tc / 2, L.n[2] - 1);
-        const long long da = a - sd.sa, db = cb - sd.sb, dc = cc - sd.sc;
-        static const int order_mode = getenv("TTSWEEP_ORDER") ? atoi(getenv("TTSWEEP_ORDER")) : 8;
-        if (order_mode == 0) key[t] = {((long long)bt * ctiles + ct) * L.n[0] + a, t};   // plane fastest
-        else if (order_mode == 1) key[t] = {da * da + db * db + dc * dc, t};
-        else {      // runs of `order_mode` consecutive planes, runs ordered by distance
-            const long long ca = (a / order_mode) * order_mode + order_mode / 2;
-            const long long dq = ca - sd.sa;
-            key[t] = {(dq * dq + db * db + dc * dc) * 64 + a % order_mode, t};
-        }
+        const long long db = cb - sd.sb, dc = cc - sd.sc;
+        // runs of RUN consecutive planes (the planes a tile stages are then mostly L2 hits
+        // left by its predecessor), runs ordered by distance from the start
+        constexpr int RUN = 8;
+        const long long ca = (a / RUN) * RUN + RUN / 2;
+        const long long dq = ca - sd.sa;
+        key[t] = {(dq * dq + db * db + dc * dc) * 64 + a % RUN, t};
     }
     std::sort(key.begin(), key.end());
     order.resize(ntiles);
@@ -620,10 +616,6 @@ int ttsweep_set_option(ttsweep_ctx *ctx, int key, long long value)
     case TTSWEEP_OPT_MAX_SWEEPS:
         if (value <= 0) return set_error("max sweeps must be positive");
         ctx->max_sweeps = value;
-        return 0;
-    case TTSWEEP_OPT_BATCH_SWEEPS:
-        if (value <= 0 || value > 1024) return set_error("batch sweeps out of range");
-        ctx->batch_sweeps = (int)value;
         return 0;
     case TTSWEEP_OPT_MAX_BATCH:
         if (value < 0) return set_error("max batch must be >= 0");
