@@ -341,3 +341,56 @@ def test_solve_multi_shards_starts_over_devices(P, golden24):
         for k, tt in zip(keys, tts):
             assert_bit_equal(tt, golden24.z[f"tt_{k}"], k)
         assert P.solve_multi(devices, golden24.v, fs, starts, tts) == 0
+
+
+def test_context_reuse_and_edge_arguments(P, golden24, oracle):
+    """One context, several solves with different start counts; zero starts; a second
+    velocity volume; a start on every face of the grid; bad arguments raise."""
+    offs = golden24.star("5")
+    fs = P.inputs.make_fs(offs)
+    ofs = oracle.make_star(offs)
+    v1 = golden24.v
+    v2 = (golden24.v * np.float32(1.7)).astype(np.float32)
+    nx, ny, nz = v1.shape
+    faces = np.array([[0, 5, 5], [nx - 1, 5, 5], [5, 0, 5], [5, ny - 1, 5], [5, 5, 0], [5, 5, nz - 1],
+                      [nx - 1, ny - 1, nz - 1]], dtype=np.int32)
+
+    def boxes(starts):
+        out = []
+        for st in starts:
+            tt = np.full(v1.shape, np.inf, dtype=np.float32)
+            tt[tuple(st)] = 0
+            out.append(tt)
+        return out
+
+    with P.TravelTimeSolver(v1.shape, fs) as sol:
+        sol.set_velocity(v1)
+        assert sol.solve(np.zeros((0, 3), np.int32), []) == 0
+        for v, group in ((v1, faces[:2]), (v1, faces), (v2, faces[3:4]), (v1, faces[4:])):
+            sol.set_velocity(v)
+            tts = boxes(group)
+            assert sol.solve(group, tts) == 1
+            for st, tt in zip(group, tts):
+                want, _, _ = oracle.converge(v, ofs, st, order=1)
+                assert_bit_equal(tt, want, f"start {st}")
+        with pytest.raises(P.TTSweepError):
+            sol.solve(np.array([[nx, 0, 0]], np.int32), boxes([[0, 0, 0]]))
+    with pytest.raises(P.TTSweepError):
+        P.TravelTimeSolver((0, 4, 4), fs)
+    with pytest.raises(P.TTSweepError):
+        P.TravelTimeSolver(v1.shape, fs, device=99)
+
+
+def test_duplicate_and_zero_offsets_in_the_star(P, oracle):
+    """A star file may repeat an offset or contain (0,0,0); both are harmless in the
+    reference and must be here (pull star: duplicates merged, zero dropped)."""
+    rng = np.random.default_rng(21)
+    shape = (18, 40, 22)
+    v = rng.uniform(0.1, 0.5, size=shape).astype(np.float32)
+    offs = np.array([[1, 0, 0], [0, 0, 0], [1, 0, 0], [0, -2, 1], [-1, 0, 0], [0, 2, -1], [0, 0, 3],
+                     [0, 0, -3], [3, 3, 3]], np.int32)
+    for start in ((9, 20, 11), (0, 0, 0)):
+        want, _, _ = oracle.converge(v, oracle.make_star(offs), start, order=1)
+        for kernel in (1, 2):
+            (tt,), _, _ = gpu_converge(P, v, P.inputs.make_fs(offs), [start], kernel=kernel)
+            assert_bit_equal(tt, want, f"{start} kernel {kernel}")
