@@ -254,14 +254,14 @@ hipError_t launch_validate(const DevLayout &L, const float *v, const float *T, l
 // Work decomposition (device axes a, b, c; c is stride-1):
 //   workgroup = one plane a x 64 cells along b x STRIP_TC cells along c
 //   wave      = 64 lanes along b, one strip of STRIP_K consecutive c cells per lane
-// Each lane keeps acc[K] (best travel time so far) and vc[K] (own velocities) in
-// registers.  For every plane offset da the workgroup stages the neighbour
-// plane's (64 + 2 rb) x (TC + 16) window of v and T into LDS once; then for
-// every (da, db) column of the star a lane reads ONE register window of
-// K + 16 neighbour values (8 ds_read_b128 per array, conflict-free by the odd
-// row pitch) and relaxes all offsets dc of that column against it: each
+// Each lane keeps acc[K] (best travel time so far) and its own velocities (as
+// register pairs) in registers.  For every plane offset da the workgroup stages
+// the neighbour plane's (64 + 2 rb) x (TC + 16) window of v and T into LDS once;
+// then for every (da, db) column of the star a lane reads ONE register window of
+// K + 16 neighbour values (up to 8 ds_read_b128 per array, conflict-free by the
+// odd row pitch) and relaxes all offsets dc of that column against it: each
 // loaded value is reused for up to 15 offsets, which is what keeps the kernel
-// VALU-bound instead of LDS-bound ("STRIP kernel").
+// VALU-bound instead of LDS-bound.
 //
 // The relaxation is branch-free: there are no bounds tests (halo cells hold
 // +INF / 0) and no liveness tests.  The few cells that own a dead edge (inside
