@@ -272,6 +272,7 @@ hipError_t launch_validate(const DevLayout &L, const float *v, const float *T, l
 constexpr int STRIP_LDS_HEAD = 16;      // floats reserved in front of the slabs
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 // A column descriptor held in scalar registers.
 struct ColRegs {
@@ -352,12 +353,17 @@ __device__ __forceinline__ void relax_column(const ColRegs &cur, const float *pv
                 for (int j = 0; j < W / 4; j++)
                     if (4 * j + 3 >= t && 4 * j <= t + K - 1) chunks |= 1u << j;
     }
+    const f32x4 *pv4 = reinterpret_cast<const f32x4 *>(__builtin_assume_aligned(pv, 16));
+    const f32x4 *pt4 = reinterpret_cast<const f32x4 *>(__builtin_assume_aligned(pt, 16));
     f32x2 vN2[W / 2], tN2[W / 2];       // window element w is pair w/2, half w&1
 #pragma unroll
     for (int j = 0; j < W / 4; j++) {
         if (chunks & (1u << j)) {
-            const float4 x = *reinterpret_cast<const float4 *>(pv + 4 * j);
-            const float4 y = *reinterpret_cast<const float4 *>(pt + 4 * j);
+            const f32x4 x = pv4[j];
+            const f32x4 y = pt4[j];
+            // keep whole float4s: when a chunk is only partly used the compiler narrows the
+            // load and pairs the pieces into ds_read2_b64 (8 LDS cycles instead of 4)
+            asm volatile("" :: "v"(x), "v"(y));
             vN2[2 * j] = f32x2{x.x, x.y}; vN2[2 * j + 1] = f32x2{x.z, x.w};
             tN2[2 * j] = f32x2{y.x, y.y}; tN2[2 * j + 1] = f32x2{y.z, y.w};
         }
