@@ -87,8 +87,13 @@ struct ttsweep_ctx {
     size_t worklist_cap[2] = {0, 0};
     long long worklist_len[2] = {0, 0};
     std::vector<std::vector<int>> tile_order[2];    // per start: tile ids, nearest to the start first
-    long long coop_below = 3000;            // units relaxed in a pass below which the next
-                                            // pass uses one-unit workgroups
+    // Distance gate (see sweep_strip_kernel): radius of the first pass and cells it opens per
+    // pass.  Defaults follow the star's reach: final values spread at about half the reach
+    // per pass (measured, 818-offset star: 3.5 cells/pass gives the shortest solve).
+    double gate_speed = 0.0;                // 0: no gate
+    double gate_r0 = 0.0;
+    double coop_density = 0.5;              // fraction of all units relaxed in a pass below
+                                            // which the next pass uses one-unit workgroups
     int *d_tile_flags = nullptr;            // capacity_starts x 2 x tiles
     unsigned long long *d_work = nullptr;   // capacity_starts
     unsigned long long *h_work = nullptr;   // pinned
@@ -317,6 +322,10 @@ static int upload_star(ttsweep_ctx *ctx)
     return 0;
 }
 
+// Activity words of one start: two parities of unit flags, the held-back plane bits and the
+// number of source units (see sweep_strip_kernel).
+static size_t flag_words(const DevLayout &L) { return 3 * (size_t)std::max(strip_units(L), 1) + 4; }
+
 static int ensure_capacity(ttsweep_ctx *ctx, int nstart)
 {
     if (nstart <= ctx->capacity_starts && ctx->d_T) return 0;
@@ -343,7 +352,7 @@ static int ensure_capacity(ttsweep_ctx *ctx, int nstart)
     HIPCHK(hipHostMalloc((void **)&ctx->h_active, nstart * sizeof(int)));
     HIPCHK(hipHostMalloc((void **)&ctx->h_changed, PASS_SLOTS * nstart * sizeof(int)));
     HIPCHK(hipMalloc((void **)&ctx->d_tile_flags,
-                     (size_t)nstart * 2 * std::max(strip_units(ctx->L), 1) * sizeof(int)));
+                     (size_t)nstart * flag_words(ctx->L) * sizeof(int)));
     HIPCHK(hipMalloc((void **)&ctx->d_work, 3 * nstart * sizeof(unsigned long long)));
     HIPCHK(hipHostMalloc((void **)&ctx->h_work, 3 * nstart * sizeof(unsigned long long)));
     ctx->capacity_starts = nstart;
@@ -442,6 +451,18 @@ static void order_tiles(const ttsweep_ctx *ctx, const StartDesc &sd, int shape, 
     for (int t = 0; t < ntiles; t++) order[t] = key[t].second;
 }
 
+// Squared radius (cells) of the distance gate for the pass about to be launched.
+static float gate_r2(const ttsweep_ctx *ctx)
+{
+    if (ctx->gate_speed <= 0) return 3.0e38f;       // gate disabled
+    const double r = ctx->gate_r0 + ctx->gate_speed * (double)ctx->pass_index;
+    return (float)(r * r);
+}
+
+#ifdef TTSWEEP_PROFILE
+namespace ttsweep { void prof_dump(); }
+#endif
+
 // One full-grid pass for the active starts.
 static int launch_pass(ttsweep_ctx *ctx, int nactive, int *d_changed, int shape)
 {
@@ -450,7 +471,8 @@ static int launch_pass(ttsweep_ctx *ctx, int nactive, int *d_changed, int shape)
     if (ctx->kernel == TTSWEEP_KERNEL_STRIP) {
         HIPCHK(launch_sweep_strip(ctx->L, ctx->d_v, ctx->d_starts, ctx->d_worklist[shape],
                                   ctx->worklist_len[shape], shape == 1, d_changed,
-                                  ctx->d_strip_cols, ctx->plan, ctx->pass_index & 1, ctx->stream));
+                                  ctx->d_strip_cols, ctx->plan, ctx->pass_index & 1,
+                                  gate_r2(ctx), ctx->stream));
         HIPCHK(launch_sweep_special(ctx->L, ctx->d_v, ctx->d_starts, ctx->d_active, nactive,
                                     d_changed, ctx->d_cell_entries, ctx->n_cell_entries,
                                     ctx->max_box_cells, ctx->pass_index & 1, ctx->stream));
@@ -525,6 +547,11 @@ ttsweep_ctx *ttsweep_create(int device, int nx, int ny, int nz, const ttsweep_fs
     ctx->nx = nx; ctx->ny = ny; ctx->nz = nz;
     ctx->pull = build_pull_star(fs, starstart, starstop);
     ctx->radius = pull_star_radius(ctx->pull);
+    ctx->gate_speed = std::max(1.0, 0.5 * ctx->radius);
+    ctx->gate_r0 = ctx->radius + 1.0;
+    if (const char *env = getenv("TTSWEEP_GATE_SPEED")) ctx->gate_speed = atof(env);    // experiments
+    if (const char *env = getenv("TTSWEEP_GATE_R0")) ctx->gate_r0 = atof(env);
+    if (const char *env = getenv("TTSWEEP_COOP_DENSITY")) ctx->coop_density = atof(env);
     ctx->relax_per_sweep = ttsweep_relaxations_per_sweep(nx, ny, nz, fs, starstart, starstop);
     ctx->kernel = strip_supported(ctx) ? TTSWEEP_KERNEL_STRIP : TTSWEEP_KERNEL_CELL;
     if (const char *env = getenv("TTSWEEP_KERNEL")) {
@@ -686,12 +713,12 @@ int ttsweep_solve_device(ttsweep_ctx *ctx, int nstart, const ttsweep_start *star
             for (int d = 0; d < 3; d++) vol *= std::max(sd.box_hi[d] - sd.box_lo[d] + 1, 0);
             ctx->max_box_cells = std::max<long long>(s == 0 ? 0 : ctx->max_box_cells, vol);
         }
-        sd.tile_flags = ctx->d_tile_flags + (size_t)s * 2 * std::max(strip_units(L), 1);
+        sd.tile_flags = ctx->d_tile_flags + (size_t)s * flag_words(L);
         sd.work = ctx->d_work + 3 * s;
         if (init) HIPCHK(launch_init_tt(L, sd.T, sd.sidx, ctx->stream));
         else HIPCHK(launch_pack(L, tt_dev[s], sd.T, INFINITY, ctx->stream));
         if (ctx->kernel == TTSWEEP_KERNEL_STRIP) {
-            HIPCHK(launch_init_tile_flags(L, sd, /*all_active=*/!init, ctx->stream));
+            HIPCHK(launch_init_tile_flags(L, sd, /*from_box=*/!init, ctx->stream));
             for (int shape = 0; shape < 2; shape++) {
                 if ((int)ctx->tile_order[shape].size() < nstart) ctx->tile_order[shape].resize(nstart);
                 order_tiles(ctx, sd, shape, ctx->tile_order[shape][s]);
@@ -714,14 +741,13 @@ int ttsweep_solve_device(ttsweep_ctx *ctx, int nstart, const ttsweep_start *star
     // that was launched speculatively for it finds all its units inactive.
     std::vector<int> sweeps(nstart, 0);
     const bool trace = getenv("TTSWEEP_TRACE") != nullptr;
-    unsigned long long trace_prev = 0, trace_prev_wg = 0;
+    unsigned long long trace_prev = 0, trace_prev_wg = 0, trace_prev_un = 0;
     std::vector<int> snapshot[PASS_SLOTS];      // active starts of each pass in flight
     // workgroup shape of the next pass: one-unit (COOP) workgroups while only a thin front is
     // active, tiles of STRIP_NS units when the pass fills the machine.  The number of units
     // relaxed per pass is read back with the "changed" words (so it lags one pass).
     int shape = 1;                              // the first passes only touch the start's surroundings
     unsigned long long units_prev = 0;
-    if (const char *env = getenv("TTSWEEP_COOP_BELOW")) ctx->coop_below = atoll(env);
     if (ctx->h_units_cap < (size_t)PASS_SLOTS * 3 * nstart) {
         if (ctx->h_units) HIPCHK(hipHostFree(ctx->h_units));
         ctx->h_units = nullptr;
@@ -756,24 +782,28 @@ int ttsweep_solve_device(ttsweep_ctx *ctx, int nstart, const ttsweep_start *star
         if (ctx->kernel == TTSWEEP_KERNEL_STRIP) {
             unsigned long long units = 0;
             for (int s = 0; s < nstart; s++) units += h_units[(size_t)slot * 3 * nstart + 3 * s + 2];
-            shape = (long long)(units - units_prev) < ctx->coop_below ? 1 : 0;
+            const double all_units = (double)snapshot[slot].size() * strip_units(L);
+            shape = (double)(units - units_prev) < ctx->coop_density * all_units ? 1 : 0;
             units_prev = units;
         }
         if (trace) {    // TTSWEEP_TRACE=1: per-pass activity on stderr (serialises the passes)
             HIPCHK(hipStreamSynchronize(ctx->stream));
             HIPCHK(hipMemcpy(ctx->h_work, ctx->d_work, 3 * nstart * sizeof(unsigned long long),
                              hipMemcpyDeviceToHost));
-            unsigned long long tot = 0, wgs = 0;
-            for (int s = 0; s < nstart; s++) { tot += ctx->h_work[3 * s]; wgs += ctx->h_work[3 * s + 1]; }
+            unsigned long long tot = 0, wgs = 0, un = 0;
+            for (int s = 0; s < nstart; s++) {
+                tot += ctx->h_work[3 * s]; wgs += ctx->h_work[3 * s + 1]; un += ctx->h_work[3 * s + 2];
+            }
             const double us = std::chrono::duration<double, std::micro>(
                                   std::chrono::steady_clock::now() - t_pass).count();
             t_pass = std::chrono::steady_clock::now();
             fprintf(stderr, "ttsweep pass %d: %d active starts, %.3f full-sweep equivalents relaxed, "
-                    "%llu workgroups ran, %.0f us, next shape %d\n", processed + 1, (int)snapshot[slot].size(),
+                    "%llu workgroups ran, %llu units, %.0f us, next shape %d\n", processed + 1, (int)snapshot[slot].size(),
                     (double)(tot - trace_prev) / (double)ctx->stats.cells
                         / (double)std::max<size_t>(ctx->pull.size(), 1),
-                    wgs - trace_prev_wg, us, shape);
+                    wgs - trace_prev_wg, un - trace_prev_un, us, shape);
             trace_prev = tot;
+            trace_prev_un = un;
             trace_prev_wg = wgs;
         }
         bool dropped = false;
@@ -811,6 +841,9 @@ int ttsweep_solve_device(ttsweep_ctx *ctx, int nstart, const ttsweep_start *star
     HIPCHK(hipEventRecord(ctx->ev_solve1, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
 
+#ifdef TTSWEEP_PROFILE
+    prof_dump();
+#endif
     float ms = 0;
     HIPCHK(hipEventElapsedTime(&ms, ctx->ev_solve0, ctx->ev_solve1));
     ctx->stats.solve_ms = ms;

@@ -48,13 +48,13 @@ int strip_units(const DevLayout &L);            // activity units (one per wave)
 hipError_t launch_sweep_strip(const DevLayout &L, const float *v, const StartDesc *starts,
                               const int2 *work, long long nblocks, bool coop, int *changed,
                               const StripCol *cols, const StripPlan &plan, int parity,
-                              hipStream_t st);
+                              float gate_r2, hipStream_t st);
 hipError_t launch_sweep_special(const DevLayout &L, const float *v, const StartDesc *starts,
                                 const int *active, int nactive, int *changed,
                                 const CellEntry *entries, int nentries, int max_box_cells,
                                 int parity, hipStream_t st);
 // flags[1][*] = all_active ? 1 : (tile == start's tile); flags[0][*] = 0
-hipError_t launch_init_tile_flags(const DevLayout &L, const StartDesc &sd, bool all_active,
+hipError_t launch_init_tile_flags(const DevLayout &L, const StartDesc &sd, bool from_box,
                                   hipStream_t st);
 
 } // namespace ttsweep

@@ -8,6 +8,7 @@
 // Halving is exact, so folding "/ 2.0" into h on the host leaves every bit
 // unchanged (fl(d*s)/2 == fl((d/2)*s) for normal floats).
 #include "ttsweep_kernels.h"
+#include <cstdio>
 
 #include <algorithm>
 #include <cstdlib>
@@ -424,12 +425,21 @@ __device__ __forceinline__ void relax_column(const ColRegs &cur, const float *pv
 //                 themselves and min-combine their partial results through LDS.  Four
 //                 times shorter critical path per unit; the shape for passes in which only
 //                 a thin front is active and the pass time is the time of one workgroup.
+#ifdef TTSWEEP_PROFILE
+__device__ unsigned long long g_prof[8];
+#define PROF_T(x) const long long x = clock64()
+#define PROF_ADD(i, v) do { if (lane == 0) atomicAdd(&g_prof[i], (unsigned long long)(v)); } while (0)
+#else
+#define PROF_T(x)
+#define PROF_ADD(i, v)
+#endif
+
 template <int K, bool COOP>
 __global__ void __launch_bounds__(STRIP_TB *(STRIP_TC / K), 3)
 sweep_strip_kernel(DevLayout L, const float *__restrict__ v,
                    const StartDesc *__restrict__ starts, const int2 *__restrict__ work,
                    int *__restrict__ changed, const StripCol *__restrict__ cols,
-                   StripPlan plan, int btiles, int ctiles, int parity)
+                   StripPlan plan, int btiles, int ctiles, int parity, float gate_r2)
 {
     static_assert(STRIP_TC % K == 0 && K % 4 == 0, "strips must tile the workgroup tile");
     constexpr int NS = STRIP_TC / K;            // waves per workgroup
@@ -443,6 +453,7 @@ sweep_strip_kernel(DevLayout L, const float *__restrict__ v,
     // ttsweep_api.cpp): entries are ordered so that consecutive blocks of one XCD
     // (blocks b, b+8, b+16, ... share an XCD and its L2) walk the tiles of "their"
     // starts from the start point outwards.
+    PROF_T(t_begin);
     const int2 item = work[blockIdx.x];
     const int s = item.x;
     if (item.y < 0) return;                 // padding entry
@@ -492,6 +503,30 @@ sweep_strip_kernel(DevLayout L, const float *__restrict__ v,
 #pragma unroll
         for (int w = 32; w >= 1; w >>= 1) my_planes |= __shfl_xor(my_planes, w);
     }
+    // ---- distance gate.  Far from the start the first values to arrive (over long edges)
+    // are poor and get refined pass after pass; relaxing those units early is wasted work.
+    // A unit is therefore held back until the gate radius (it grows by a fixed number of
+    // cells per pass) reaches it.  What it has to relax is remembered in pend[] (plane
+    // bits accumulate across passes), so holding a unit back never loses an update, and a
+    // start with anything pending is not reported as converged.
+    unsigned *__restrict__ pend = reinterpret_cast<unsigned *>(sd.tile_flags + 2 * nunits);
+    unsigned held;
+    {
+        const int cb0 = c0 + strip * K;
+        const float da_ = (float)abs(a - sd.sa);
+        const float db_ = (float)max(max(b0 - sd.sb, sd.sb - (b0 + tb_eff - 1)), 0);
+        const float dc_ = (float)max(max(cb0 - sd.sc, sd.sc - (cb0 + K - 1)), 0);
+        // (the gate is for solves that grow from one source unit; a box that arrives with
+        // many finite units, e.g. an already converged one, is relaxed ungated)
+        const bool gated = sd.tile_flags[3 * nunits] == 1;
+        const bool open = !gated || da_ * da_ + db_ * db_ + dc_ * dc_ <= gate_r2;
+        held = pend[my_unit];       // COOP: every wave reads it; it is cleared in the epilogue
+        if (!open && lane == 0 && (!COOP || wave == 0)) {
+            if (my_planes & ~held) pend[my_unit] = held | my_planes;
+            if (held | my_planes) atomicOr(&changed[s], 1);        // work is waiting
+        }
+        my_planes = open ? (my_planes | held) : 0u;
+    }
     const bool wave_active = my_planes != 0;
     const unsigned wg_planes = COOP ? my_planes : block_or_mask<NS>(my_planes, smem, wave, lane);
     if (wg_planes == 0) {
@@ -500,6 +535,10 @@ sweep_strip_kernel(DevLayout L, const float *__restrict__ v,
     }
 
     if (tid == 0) atomicAdd(sd.work + 1, 1ull);     // workgroups that had to run (statistics)
+    PROF_T(t_active);
+#ifdef TTSWEEP_PROFILE
+    long long p_wait = 0, p_stage = 0, p_comp = 0;
+#endif
 
     float *sv = smem + STRIP_LDS_HEAD;
     float *sT = sv + rows * PW;
@@ -531,7 +570,9 @@ sweep_strip_kernel(DevLayout L, const float *__restrict__ v,
         // ---- stage plane a+da: rows b0-rb .. b0+63+rb, columns c0-CF .. c0+TC+CF-1
         const long long src = (long long)(a + da + L.lo[0]) * L.s0
                             + (long long)(b0 - rb + L.lo[1]) * L.s1 + (c0 - STRIP_CF + L.lo[2]);
+        PROF_T(t0);
         __syncthreads();            // everybody is done reading the previous slab
+        PROF_T(t1);
         for (int f = tid; f < nf4; f += NT) {
             const int r = f / F4_PER_ROW;
             const int c4 = f - r * F4_PER_ROW;
@@ -542,6 +583,10 @@ sweep_strip_kernel(DevLayout L, const float *__restrict__ v,
             *reinterpret_cast<float4 *>(sT + r * PW + 4 * c4) = xt;
         }
         __syncthreads();
+        PROF_T(t2);
+#ifdef TTSWEEP_PROFILE
+        p_wait += t1 - t0; p_stage += t2 - t1;
+#endif
 
         // ---- relax every column of this plane offset.  The column descriptor lives
         // in SGPRs; the NEXT column's descriptor is requested before this column's
@@ -567,7 +612,11 @@ sweep_strip_kernel(DevLayout L, const float *__restrict__ v,
             }
             cur = nxt;
         }
+#ifdef TTSWEEP_PROFILE
+        p_comp += clock64() - t2;
+#endif
     }
+    PROF_T(t_loop);
 
     if (COOP) {
         // min-combine the waves' partial results: [wave][cell][lane] floats in LDS
@@ -608,6 +657,7 @@ sweep_strip_kernel(DevLayout L, const float *__restrict__ v,
         cur_flags[my_unit] = improved;
         if (any) atomicOr(&changed[s], 1);
         if (wave_active) {
+            if (held) pend[my_unit] = 0;        // what was held back has now been relaxed
             const int wb = min(tb_eff, L.n[1] - b0), wc = max(min(K, L.n[2] - cbase), 0);
             int nent = 0;
             for (int ia = 0; ia <= 2 * plan.ra; ia++)
@@ -616,7 +666,27 @@ sweep_strip_kernel(DevLayout L, const float *__restrict__ v,
             atomicAdd(sd.work + 2, 1ull);       // units relaxed (drives the choice of workgroup shape)
         }
     }
+#ifdef TTSWEEP_PROFILE
+    {
+        const long long t_end = clock64();
+        PROF_ADD(0, t_active - t_begin); PROF_ADD(1, p_wait); PROF_ADD(2, p_stage); PROF_ADD(3, p_comp);
+        PROF_ADD(4, t_end - t_loop); PROF_ADD(5, t_end - t_begin); PROF_ADD(6, 1);
+    }
+#endif
 }
+
+#ifdef TTSWEEP_PROFILE
+void prof_dump()
+{
+    unsigned long long h[8] = {};
+    (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(g_prof), sizeof(h));
+    const double n = (double)std::max<unsigned long long>(h[6], 1);
+    fprintf(stderr, "prof (wave 0 of %llu active WGs, cycles/WG): prologue %.0f  wait %.0f  stage %.0f  compute %.0f  epilogue %.0f  total %.0f\n",
+            h[6], h[0] / n, h[1] / n, h[2] / n, h[3] / n, h[4] / n, h[5] / n);
+    unsigned long long z[8] = {};
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_prof), z, sizeof(z));
+}
+#endif
 
 int strip_tiles(const DevLayout &L)
 {
@@ -633,10 +703,38 @@ init_tile_flags_kernel(int *__restrict__ flags, int nunits, int start_unit)
     const int t = blockIdx.x * 256 + threadIdx.x;
     if (t >= nunits) return;
     flags[t] = 0;
-    flags[nunits + t] = (start_unit < 0 || t == start_unit) ? 7 : 0;
+    flags[nunits + t] = t == start_unit ? 7 : 0;
+    flags[2 * nunits + t] = 0;          // pend[]: nothing held back yet
+    if (t == 0) flags[3 * nunits] = 1;  // one source unit: the distance gate applies
 }
 
-hipError_t launch_init_tile_flags(const DevLayout &L, const StartDesc &sd, bool all_active,
+// Flags for a box that arrives with values in it: a unit counts as "changed" when it holds
+// a finite travel time (only those can improve anything).  One wave per unit.
+__global__ void __launch_bounds__(64)
+init_tile_flags_box_kernel(DevLayout L, const float *__restrict__ T, int *__restrict__ flags,
+                           int nunits, int btiles, int cstrips)
+{
+    int u = blockIdx.x;
+    const int cs = u % cstrips;  u /= cstrips;
+    const int bt = u % btiles;   u /= btiles;
+    const int a = u;
+    const int lane = threadIdx.x;
+    const long long g = (long long)(a + L.lo[0]) * L.s0
+                      + (long long)(bt * STRIP_TB + lane + L.lo[1]) * L.s1 + (cs * STRIP_K + L.lo[2]);
+    bool finite = false;
+    if (bt * STRIP_TB + lane < L.n[1])
+#pragma unroll
+        for (int q = 0; q < STRIP_K; q++) finite |= T[g + q] < __builtin_inff();
+    const bool any = __ballot(finite) != 0ull;
+    if (lane == 0) {
+        flags[blockIdx.x] = 0;
+        flags[nunits + blockIdx.x] = any ? 7 : 0;
+        flags[2 * nunits + blockIdx.x] = 0;
+        if (any) atomicAdd(&flags[3 * nunits], 1);      // number of source units
+    }
+}
+
+hipError_t launch_init_tile_flags(const DevLayout &L, const StartDesc &sd, bool from_box,
                                   hipStream_t st)
 {
     constexpr int k = STRIP_K;
@@ -644,8 +742,14 @@ hipError_t launch_init_tile_flags(const DevLayout &L, const StartDesc &sd, bool 
     const int ctiles = (L.n[2] + STRIP_TC - 1) / STRIP_TC;
     const int cstrips = ctiles * (STRIP_TC / k);
     const int nunits = L.n[0] * btiles * cstrips;
-    const int start_unit = all_active ? -1
-        : (sd.sa * btiles + sd.sb / STRIP_TB) * cstrips + sd.sc / k;
+    if (from_box) {
+        hipError_t e = hipMemsetAsync(sd.tile_flags + 3 * (size_t)nunits, 0, sizeof(int), st);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(init_tile_flags_box_kernel, dim3(nunits), dim3(64), 0, st, L, sd.T,
+                           sd.tile_flags, nunits, btiles, cstrips);
+        return hipGetLastError();
+    }
+    const int start_unit = (sd.sa * btiles + sd.sb / STRIP_TB) * cstrips + sd.sc / k;
     hipLaunchKernelGGL(init_tile_flags_kernel, dim3((nunits + 255) / 256), dim3(256), 0, st,
                        sd.tile_flags, nunits, start_unit);
     return hipGetLastError();
@@ -664,7 +768,7 @@ template <int K, bool COOP>
 static hipError_t launch_strip_k(const DevLayout &L, const float *v, const StartDesc *starts,
                                  const int2 *work, long long nblocks, int *changed,
                                  const StripCol *cols, const StripPlan &plan, int parity,
-                                 hipStream_t st)
+                                 float gate_r2, hipStream_t st)
 {
     const int btiles = (L.n[1] + STRIP_TB - 1) / STRIP_TB;
     const int ctiles = COOP ? strip_cstrips(L) : (L.n[2] + STRIP_TC - 1) / STRIP_TC;
@@ -676,20 +780,22 @@ static hipError_t launch_strip_k(const DevLayout &L, const float *v, const Start
         if (e != hipSuccess) return e;
     }
     hipLaunchKernelGGL(kern, dim3((unsigned)nblocks), dim3(STRIP_TB, STRIP_TC / K), lds, st, L, v,
-                       starts, work, changed, cols, plan, btiles, ctiles, parity);
+                       starts, work, changed, cols, plan, btiles, ctiles, parity, gate_r2);
     return hipGetLastError();
 }
 
 hipError_t launch_sweep_strip(const DevLayout &L, const float *v, const StartDesc *starts,
                               const int2 *work, long long nblocks, bool coop, int *changed,
                               const StripCol *cols, const StripPlan &plan, int parity,
-                              hipStream_t st)
+                              float gate_r2, hipStream_t st)
 {
     if (nblocks <= 0) return hipSuccess;
     if (nblocks > 0x7fffffffLL) return hipErrorInvalidValue;
     if (coop)
-        return launch_strip_k<STRIP_K, true>(L, v, starts, work, nblocks, changed, cols, plan, parity, st);
-    return launch_strip_k<STRIP_K, false>(L, v, starts, work, nblocks, changed, cols, plan, parity, st);
+        return launch_strip_k<STRIP_K, true>(L, v, starts, work, nblocks, changed, cols, plan, parity,
+                                             gate_r2, st);
+    return launch_strip_k<STRIP_K, false>(L, v, starts, work, nblocks, changed, cols, plan, parity,
+                                          gate_r2, st);
 }
 
 // ===========================================================================
