@@ -86,6 +86,11 @@ struct ttsweep_ctx {
     int2 *d_worklist[2] = {nullptr, nullptr};
     size_t worklist_cap[2] = {0, 0};
     long long worklist_len[2] = {0, 0};
+    // unit queues of a sparse pass (plan_pass_kernel -> sweep_units_kernel)
+    int4 *d_unitq = nullptr;                // UNITQ_LISTS lists of unitq_cap entries
+    size_t unitq_cap = 0;
+    int *d_unitq_ctrl = nullptr;            // UNITQ_CTRL_WORDS (counts, cursors)
+    int unitq_blocks = 0;                   // persistent grid: workgroups the device holds at once
     std::vector<std::vector<int>> tile_order[2];    // per start: tile ids, nearest to the start first
     // Distance gate (see sweep_strip_kernel): radius of the first pass and cells it opens per
     // pass.  Defaults follow the star's reach: final values spread at about half the reach
@@ -233,9 +238,30 @@ static int upload_strip_plan(ttsweep_ctx *ctx)
     std::vector<StripCol> flat;
     for (int ia = 0; ia <= 2 * plan.ra; ia++) {
         plan.first[ia] = (int)flat.size();
-        flat.insert(flat.end(), per_plane[ia].begin(), per_plane[ia].end());
         plan.nent[ia] = 0;
         for (const auto &c : per_plane[ia]) plan.nent[ia] += __builtin_popcount(c.mask);
+        // Four shares of nearly equal cost for the unit-queue kernel's waves (longest
+        // processing time first; a column costs its offsets plus a fixed part for the
+        // window loads), each share contiguous in the flat list.
+        std::vector<StripCol> cols = per_plane[ia];
+        std::stable_sort(cols.begin(), cols.end(), [](const StripCol &x, const StripCol &y) {
+            return __builtin_popcount(x.mask) > __builtin_popcount(y.mask);
+        });
+        std::vector<StripCol> share[STRIP_NS];
+        int cost[STRIP_NS] = {};
+        for (const auto &c : cols) {
+            int w = 0;
+            for (int k = 1; k < STRIP_NS; k++)
+                if (cost[k] < cost[w]) w = k;
+            share[w].push_back(c);
+            cost[w] += __builtin_popcount(c.mask) + 2;
+        }
+        if (cols.size() > 255) return set_error("star has too many columns per plane offset");
+        plan.wsplit[ia][0] = 0;
+        for (int w = 0; w < STRIP_NS; w++) {
+            flat.insert(flat.end(), share[w].begin(), share[w].end());
+            plan.wsplit[ia][w + 1] = (unsigned char)(plan.wsplit[ia][w] + share[w].size());
+        }
     }
     plan.first[2 * plan.ra + 1] = (int)flat.size();
     if (ctx->d_strip_cols) HIPCHK(hipFree(ctx->d_strip_cols));
@@ -417,6 +443,22 @@ static int build_worklist_shape(ttsweep_ctx *ctx, int nactive, int shape)
                           hipMemcpyHostToDevice, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));      // `flat` is a stack-lifetime buffer
     ctx->worklist_len[shape] = (long long)flat.size();
+    if (shape == 1) {       // queues that can hold every unit of the list
+        const size_t cap = longest;
+        if (cap > ctx->unitq_cap) {
+            if (ctx->d_unitq) HIPCHK(hipFree(ctx->d_unitq));
+            ctx->d_unitq = nullptr;
+            HIPCHK(hipMalloc((void **)&ctx->d_unitq, cap * UNITQ_LISTS * sizeof(int4)));
+            ctx->unitq_cap = cap;
+        }
+        if (!ctx->d_unitq_ctrl) HIPCHK(hipMalloc((void **)&ctx->d_unitq_ctrl, UNITQ_CTRL_WORDS * sizeof(int)));
+        if (ctx->unitq_blocks == 0) {
+            hipDeviceProp_t prop;
+            HIPCHK(hipGetDeviceProperties(&prop, ctx->device));
+            const int wgs = 3 * std::max(prop.multiProcessorCount, 1);     // 3 workgroups (12 waves) per CU
+            ctx->unitq_blocks = ((wgs + UNITQ_LISTS - 1) / UNITQ_LISTS) * UNITQ_LISTS;
+        }
+    }
     return 0;
 }
 
@@ -469,10 +511,20 @@ static int launch_pass(ttsweep_ctx *ctx, int nactive, int *d_changed, int shape)
     hipEvent_t e0, e1;
     if (ctx->timing && timed_event(ctx, &e0)) return -1;
     if (ctx->kernel == TTSWEEP_KERNEL_STRIP) {
-        HIPCHK(launch_sweep_strip(ctx->L, ctx->d_v, ctx->d_starts, ctx->d_worklist[shape],
-                                  ctx->worklist_len[shape], shape == 1, d_changed,
-                                  ctx->d_strip_cols, ctx->plan, ctx->pass_index & 1,
-                                  gate_r2(ctx), ctx->stream));
+        if (shape == 1) {
+            HIPCHK(hipMemsetAsync(ctx->d_unitq_ctrl, 0, UNITQ_CTRL_WORDS * sizeof(int), ctx->stream));
+            HIPCHK(launch_plan_pass(ctx->L, ctx->d_starts, ctx->d_worklist[1], ctx->worklist_len[1],
+                                    d_changed, ctx->d_unitq, (int)ctx->unitq_cap, ctx->d_unitq_ctrl,
+                                    ctx->plan, ctx->pass_index & 1, gate_r2(ctx), ctx->stream));
+            HIPCHK(launch_sweep_units(ctx->L, ctx->d_v, ctx->d_starts, ctx->d_unitq,
+                                      (int)ctx->unitq_cap, ctx->d_unitq_ctrl, ctx->unitq_blocks,
+                                      d_changed, ctx->d_strip_cols, ctx->plan, ctx->pass_index & 1,
+                                      ctx->stream));
+        } else {
+            HIPCHK(launch_sweep_strip(ctx->L, ctx->d_v, ctx->d_starts, ctx->d_worklist[0],
+                                      ctx->worklist_len[0], false, d_changed, ctx->d_strip_cols,
+                                      ctx->plan, ctx->pass_index & 1, gate_r2(ctx), ctx->stream));
+        }
         HIPCHK(launch_sweep_special(ctx->L, ctx->d_v, ctx->d_starts, ctx->d_active, nactive,
                                     d_changed, ctx->d_cell_entries, ctx->n_cell_entries,
                                     ctx->max_box_cells, ctx->pass_index & 1, ctx->stream));
@@ -597,6 +649,8 @@ void ttsweep_destroy(ttsweep_ctx *ctx)
     (void)hipFree(ctx->d_tile_flags);
     (void)hipFree(ctx->d_worklist[0]);
     (void)hipFree(ctx->d_worklist[1]);
+    (void)hipFree(ctx->d_unitq);
+    (void)hipFree(ctx->d_unitq_ctrl);
     (void)hipFree(ctx->d_work);
     if (ctx->h_work) (void)hipHostFree(ctx->h_work);
     if (ctx->h_units) (void)hipHostFree(ctx->h_units);

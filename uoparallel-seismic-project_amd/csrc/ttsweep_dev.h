@@ -95,6 +95,15 @@ struct StripPlan {
     int ra, rb;                         // max |da|, max |db| over the star
     int first[2 * STRIP_MAX_RA + 2];    // columns of plane offset da are [first[da+ra], first[da+ra+1])
     int nent[2 * STRIP_MAX_RA + 1];     // pull entries (offsets) with plane offset da
+    // unit-queue kernel: the columns of a plane offset are laid out so that wave w of the
+    // workgroup relaxes [first[ia] + wsplit[ia][w], first[ia] + wsplit[ia][w+1]) - four
+    // shares of nearly equal cost
+    unsigned char wsplit[2 * STRIP_MAX_RA + 1][STRIP_NS + 1];
 };
+
+// Unit queues of one pass (sweep_units_kernel): 8 lists, one per XCD, filled by
+// plan_pass_kernel.  ctrl[0..7] = entries in list x, ctrl[8..15] = next entry to hand out.
+constexpr int UNITQ_LISTS = 8;
+constexpr int UNITQ_CTRL_WORDS = 2 * UNITQ_LISTS;
 
 } // namespace ttsweep

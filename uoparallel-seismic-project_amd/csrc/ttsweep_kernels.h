@@ -53,6 +53,20 @@ hipError_t launch_sweep_special(const DevLayout &L, const float *v, const StartD
                                 const int *active, int nactive, int *changed,
                                 const CellEntry *entries, int nentries, int max_box_cells,
                                 int parity, hipStream_t st);
+// ---- unit queues (sparse passes) --------------------------------------------
+// plan_pass: one thread per entry of the static work list `work` (unit ids, XCD-interleaved:
+// entry i belongs to XCD i % 8).  Decides which units are due in this pass (activity flags of
+// the previous pass, distance gate, held-back plane bits) and appends (start, unit, planes)
+// to the queue of the unit's XCD; clears the unit's flag word of this pass.
+// sweep_units: a persistent grid (`nblocks` workgroups) drains the queues, own XCD first.
+size_t units_lds_bytes(const StripPlan &plan, int nb);
+hipError_t launch_plan_pass(const DevLayout &L, const StartDesc *starts, const int2 *work,
+                            long long nwork, int *changed, int4 *lists, int list_cap, int *ctrl,
+                            const StripPlan &plan, int parity, float gate_r2, hipStream_t st);
+hipError_t launch_sweep_units(const DevLayout &L, const float *v, const StartDesc *starts,
+                              const int4 *lists, int list_cap, int *ctrl, int nblocks,
+                              int *changed, const StripCol *cols, const StripPlan &plan,
+                              int parity, hipStream_t st);
 // flags[1][*] = all_active ? 1 : (tile == start's tile); flags[0][*] = 0
 hipError_t launch_init_tile_flags(const DevLayout &L, const StartDesc &sd, bool from_box,
                                   hipStream_t st);

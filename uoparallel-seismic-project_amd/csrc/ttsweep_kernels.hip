@@ -799,6 +799,291 @@ hipError_t launch_sweep_strip(const DevLayout &L, const float *v, const StartDes
 }
 
 // ===========================================================================
+// sparse passes: unit queues drained by a persistent grid
+// ===========================================================================
+//
+// With the distance gate only a shell of units is due in any pass, and most workgroups of a
+// grid-per-unit launch would start, read their neighbours' flags and leave.  Sparse passes
+// therefore run in two steps: plan_pass_kernel (one THREAD per unit) decides which units
+// are due and writes them, in work-list order, into one queue per XCD; sweep_units_kernel,
+// a grid of as many workgroups as the chip holds at once, drains the queues (own XCD's
+// first, then the others').  A workgroup relaxes ONE unit at a time, its four waves
+// splitting the star's columns among themselves (nearly equal shares, StripPlan::wsplit)
+// and min-combining their partial results through LDS.
+
+__global__ void __launch_bounds__(256)
+plan_pass_kernel(DevLayout L, const StartDesc *__restrict__ starts, const int2 *__restrict__ work,
+                 long long nwork, int *__restrict__ changed, int4 *__restrict__ lists, int list_cap,
+                 int *__restrict__ ctrl, int ra, int btiles, int cstrips, int parity, float gate_r2)
+{
+    // wave W handles 64 consecutive entries of ONE XCD's sub-list, so that a wave-level
+    // compaction keeps the work-list order (nearest to the start first) inside a queue
+    const int lane = threadIdx.x & 63;
+    const long long W = ((long long)blockIdx.x * 256 + threadIdx.x) >> 6;
+    const int x = (int)(W % UNITQ_LISTS);
+    const long long k = (W / UNITQ_LISTS) * 64 + lane;
+    const long long i = k * UNITQ_LISTS + x;
+    unsigned planes = 0;
+    int s = 0, unit = -1;
+    if (i < nwork) {
+        const int2 item = work[i];
+        s = item.x;
+        unit = item.y;
+    }
+    if (unit >= 0) {
+        const StartDesc sd = starts[s];
+        const int nunits = L.n[0] * btiles * cstrips;
+        int u = unit;
+        const int cs = u % cstrips;  u /= cstrips;
+        const int bt = u % btiles;   u /= btiles;
+        const int a = u;
+        const int *__restrict__ prev_flags = sd.tile_flags + (1 - parity) * nunits;
+        for (int ia = 0; ia <= 2 * ra; ia++) {
+            const int na = a + ia - ra;
+            if (na < 0 || na >= L.n[0]) continue;
+            bool due = false;
+            for (int r = 0; r < 9; r++) {
+                const int nb = bt + r / 3 - 1, nc = cs + r % 3 - 1;
+                const int need = (r % 3 == 0) ? FLAG_HI : (r % 3 == 2) ? FLAG_LO : FLAG_ANY;
+                if (nb >= 0 && nb < btiles && nc >= 0 && nc < cstrips
+                    && (prev_flags[(na * btiles + nb) * cstrips + nc] & need))
+                    due = true;
+            }
+            if (due) planes |= 1u << ia;
+        }
+        // distance gate and held-back plane bits: as in sweep_strip_kernel
+        unsigned *__restrict__ pend = reinterpret_cast<unsigned *>(sd.tile_flags + 2 * nunits);
+        const int b0 = bt * STRIP_TB, cb0 = cs * STRIP_K;
+        const int tb_eff = min(STRIP_TB, L.n[1]);
+        const float da_ = (float)abs(a - sd.sa);
+        const float db_ = (float)max(max(b0 - sd.sb, sd.sb - (b0 + tb_eff - 1)), 0);
+        const float dc_ = (float)max(max(cb0 - sd.sc, sd.sc - (cb0 + STRIP_K - 1)), 0);
+        const bool gated = sd.tile_flags[3 * nunits] == 1;
+        const bool open = !gated || da_ * da_ + db_ * db_ + dc_ * dc_ <= gate_r2;
+        const unsigned held = pend[unit];
+        if (!open) {
+            if (planes & ~held) pend[unit] = held | planes;
+            if (held | planes) atomicOr(&changed[s], 1);       // work is waiting
+            planes = 0;
+        } else {
+            planes |= held;
+            if (held) pend[unit] = 0;
+        }
+        sd.tile_flags[parity * nunits + unit] = 0;      // improvements of this pass are OR-ed in
+    }
+    const unsigned long long due_lanes = __ballot(planes != 0);
+    if (due_lanes == 0ull) return;
+    int base = 0;
+    if (lane == 0) base = atomicAdd(&ctrl[x], __popcll(due_lanes));
+    base = __shfl(base, 0);
+    if (planes != 0) {
+        const int rank = __popcll(due_lanes & ((1ull << lane) - 1ull));
+        lists[(size_t)x * list_cap + base + rank] = make_int4(s, unit, (int)planes, 0);
+    }
+}
+
+template <int K>
+__global__ void __launch_bounds__(STRIP_TB *STRIP_NS, 3)
+sweep_units_kernel(DevLayout L, const float *__restrict__ v, const StartDesc *__restrict__ starts,
+                   const int4 *__restrict__ lists, int list_cap, int *__restrict__ ctrl,
+                   int *__restrict__ changed, const StripCol *__restrict__ cols, StripPlan plan,
+                   int btiles, int cstrips, int parity)
+{
+    constexpr int NS = STRIP_NS;
+    constexpr int NT = STRIP_TB * NS;
+    constexpr int PWV = K + 2 * STRIP_CF;
+    constexpr int PW = PWV + (((PWV / 4) % 2 == 0) ? 4 : 0);
+    constexpr int F4_PER_ROW = PWV / 4;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    int *head = reinterpret_cast<int *>(smem);      // [0], [1]: queue index handed to the workgroup
+
+    const int lane = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.y);
+    const int tid = wave * STRIP_TB + lane;
+    const int rb = plan.rb;
+    const int tb_eff = min(STRIP_TB, L.n[1]);
+    const int rows = tb_eff + 2 * rb;
+    const int lane_r = min(lane, tb_eff - 1);
+    const int nf4 = rows * F4_PER_ROW;
+    const int nunits = L.n[0] * btiles * cstrips;
+    float *sv = smem + STRIP_LDS_HEAD;
+    float *sT = sv + rows * PW;
+    float *comb = smem + STRIP_LDS_HEAD;            // [wave][cell][lane], aliases the slabs
+
+    const int home = blockIdx.x % UNITQ_LISTS;
+    int probe = 0, it = 0;
+    while (probe < UNITQ_LISTS) {
+        // ---- take the next unit of queue q (every wave leaves through the same exit:
+        // all queues exhausted)
+        const int q = (home + probe) % UNITQ_LISTS;
+        const int n = ctrl[q];
+        if (tid == 0) head[it & 1] = ctrl[UNITQ_LISTS + q] < n ? atomicAdd(&ctrl[UNITQ_LISTS + q], 1) : n;
+        __syncthreads();
+        const int j = __builtin_amdgcn_readfirstlane(head[it & 1]);
+        it++;
+        if (j >= n) { probe++; continue; }
+        const int4 item = lists[(size_t)q * list_cap + j];
+        const int s = __builtin_amdgcn_readfirstlane(item.x);
+        const int my_unit = __builtin_amdgcn_readfirstlane(item.y);
+        const unsigned my_planes = (unsigned)__builtin_amdgcn_readfirstlane(item.z);
+        int u = my_unit;
+        const int cs = u % cstrips;  u /= cstrips;
+        const int bt = u % btiles;   u /= btiles;
+        const int a = u;
+        const int b0 = bt * STRIP_TB;
+        const int c0 = cs * K;
+
+        const StartDesc sd = starts[s];
+        float *__restrict__ T = sd.T;
+        if (tid == 0) {     // statistics: cells x offsets relaxed, workgroups, units
+            const int wb = min(tb_eff, L.n[1] - b0), wc = max(min(K, L.n[2] - c0), 0);
+            int nent = 0;
+            for (int ia = 0; ia <= 2 * plan.ra; ia++)
+                if ((my_planes >> ia) & 1u) nent += plan.nent[ia];
+            atomicAdd(sd.work, (unsigned long long)(wb * wc) * (unsigned long long)nent);
+            atomicAdd(sd.work + 1, 1ull);
+            atomicAdd(sd.work + 2, 1ull);
+        }
+
+        // own cells: (a, b0 + lane, c0 + q)
+        const long long own = (long long)(a + L.lo[0]) * L.s0 + (long long)(b0 + lane_r + L.lo[1]) * L.s1
+                            + (c0 + L.lo[2]);
+        float acc[K];
+        f32x2 vce[K / 2];
+        f32x2 vco[K / 2 - 1];
+#pragma unroll
+        for (int jj = 0; jj < K / 4; jj++) {
+            const float4 xx = *reinterpret_cast<const float4 *>(v + own + 4 * jj);
+            const float4 yy = *reinterpret_cast<const float4 *>(T + own + 4 * jj);
+            vce[2 * jj] = f32x2{xx.x, xx.y}; vce[2 * jj + 1] = f32x2{xx.z, xx.w};
+            acc[4 * jj + 0] = yy.x; acc[4 * jj + 1] = yy.y; acc[4 * jj + 2] = yy.z; acc[4 * jj + 3] = yy.w;
+        }
+#pragma unroll
+        for (int p = 0; p < K / 2 - 1; p++) vco[p] = f32x2{vce[p].y, vce[p + 1].x};
+
+        for (int ia = 0; ia <= 2 * plan.ra; ia++) {
+            if (plan.first[ia] == plan.first[ia + 1] || !((my_planes >> ia) & 1u)) continue;
+            const int da = ia - plan.ra;
+            // ---- stage plane a+da: rows b0-rb .. b0+63+rb, columns c0-CF .. c0+K+CF-1
+            const long long src = (long long)(a + da + L.lo[0]) * L.s0
+                                + (long long)(b0 - rb + L.lo[1]) * L.s1 + (c0 - STRIP_CF + L.lo[2]);
+            __syncthreads();            // everybody is done reading the previous slab
+            for (int f = tid; f < nf4; f += NT) {
+                const int r = f / F4_PER_ROW;
+                const int c4 = f - r * F4_PER_ROW;
+                const long long g = src + (long long)r * L.s1 + 4 * c4;
+                const float4 xv = *reinterpret_cast<const float4 *>(v + g);
+                const float4 xt = *reinterpret_cast<const float4 *>(T + g);
+                *reinterpret_cast<float4 *>(sv + r * PW + 4 * c4) = xv;
+                *reinterpret_cast<float4 *>(sT + r * PW + 4 * c4) = xt;
+            }
+            __syncthreads();
+
+            // ---- this wave's share of the plane offset's columns
+            const int cbeg = plan.first[ia] + plan.wsplit[ia][wave];
+            const int cend = plan.first[ia] + plan.wsplit[ia][wave + 1];
+            if (cbeg >= cend) continue;
+            ColRegs cur = load_col(cols, cbeg);
+            for (int ci = cbeg; ci < cend; ci++) {
+                pin_col(cur);
+                const ColRegs nxt = load_col(cols, min(ci + 1, cend - 1));
+                const float *pv = sv + (lane_r + rb + cur.rowoff) * PW;
+                const float *pt = pv + rows * PW;
+                switch (cur.mask) {
+#define STRIP_MASK_CASE(m) case m: relax_column<K, m>(cur, pv, pt, vce, vco, acc); break;
+#include "strip_masks.inc"
+#undef STRIP_MASK_CASE
+                default: relax_column<K, 0u>(cur, pv, pt, vce, vco, acc); break;
+                }
+                cur = nxt;
+            }
+        }
+
+        // ---- min-combine the waves' partial results; wave w finishes cells 4w .. 4w+3
+        __syncthreads();                // the last slab is no longer read
+#pragma unroll
+        for (int qq = 0; qq < K; qq++) comb[(wave * K + qq) * STRIP_TB + lane] = acc[qq];
+        __syncthreads();
+        constexpr int CQ = K / NS;      // cells per wave in the epilogue
+        const int q0 = wave * CQ;
+        float best[CQ];
+#pragma unroll
+        for (int qq = 0; qq < CQ; qq++) {
+            float m = comb[(0 * K + q0 + qq) * STRIP_TB + lane];
+#pragma unroll
+            for (int w = 1; w < NS; w++) m = fminf(m, comb[(w * K + q0 + qq) * STRIP_TB + lane]);
+            best[qq] = m;
+        }
+        // store improved cells that lie inside the grid and outside the dead-edge box
+        const int b = b0 + lane;
+        const bool row_ok = lane < tb_eff && b < L.n[1];
+        const bool in_box_ab = a >= sd.box_lo[0] && a <= sd.box_hi[0] && b >= sd.box_lo[1] && b <= sd.box_hi[1];
+        int improved = 0;
+#pragma unroll
+        for (int qq = 0; qq < CQ; qq++) {
+            const int cq = q0 + qq;
+            const int c = c0 + cq;
+            const bool special = in_box_ab && c >= sd.box_lo[2] && c <= sd.box_hi[2];
+            if (row_ok && c < L.n[2] && !special && best[qq] < T[own + cq]) {
+                T[own + cq] = best[qq];
+                improved |= FLAG_ANY | (cq < STRIP_CF - 1 ? FLAG_LO : 0) | (cq > K - STRIP_CF ? FLAG_HI : 0);
+            }
+        }
+#pragma unroll
+        for (int w = 32; w >= 1; w >>= 1) improved |= __shfl_xor(improved, w);
+        if (lane == 0 && improved) {
+            atomicOr(sd.tile_flags + parity * nunits + my_unit, improved);
+            atomicOr(&changed[s], 1);
+        }
+    }
+}
+
+size_t units_lds_bytes(const StripPlan &plan, int nb)
+{
+    constexpr int pwv = STRIP_K + 2 * STRIP_CF;
+    constexpr int pw = pwv + (((pwv / 4) % 2 == 0) ? 4 : 0);
+    size_t floats = (size_t)2 * (std::min(STRIP_TB, nb) + 2 * plan.rb) * pw;
+    floats = std::max(floats, (size_t)STRIP_NS * STRIP_K * STRIP_TB);       // combine buffer
+    return (floats + STRIP_LDS_HEAD) * sizeof(float);
+}
+
+hipError_t launch_plan_pass(const DevLayout &L, const StartDesc *starts, const int2 *work,
+                            long long nwork, int *changed, int4 *lists, int list_cap, int *ctrl,
+                            const StripPlan &plan, int parity, float gate_r2, hipStream_t st)
+{
+    if (nwork <= 0) return hipSuccess;
+    const int btiles = (L.n[1] + STRIP_TB - 1) / STRIP_TB;
+    // threads: waves of 64 entries, dealt over the 8 sub-lists
+    const long long per_list = (nwork + UNITQ_LISTS - 1) / UNITQ_LISTS;
+    const long long waves = ((per_list + 63) / 64) * UNITQ_LISTS;
+    const long long nblocks = (waves + 3) / 4;
+    if (nblocks > 0x7fffffffLL) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(plan_pass_kernel, dim3((unsigned)nblocks), dim3(256), 0, st, L, starts, work,
+                       nwork, changed, lists, list_cap, ctrl, plan.ra, btiles, strip_cstrips(L),
+                       parity, gate_r2);
+    return hipGetLastError();
+}
+
+hipError_t launch_sweep_units(const DevLayout &L, const float *v, const StartDesc *starts,
+                              const int4 *lists, int list_cap, int *ctrl, int nblocks,
+                              int *changed, const StripCol *cols, const StripPlan &plan,
+                              int parity, hipStream_t st)
+{
+    if (nblocks <= 0) return hipSuccess;
+    const int btiles = (L.n[1] + STRIP_TB - 1) / STRIP_TB;
+    auto kern = sweep_units_kernel<STRIP_K>;
+    const size_t lds = units_lds_bytes(plan, L.n[1]);
+    if (lds > 48 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL(kern, dim3((unsigned)nblocks), dim3(STRIP_TB, STRIP_NS), lds, st, L, v, starts,
+                       lists, list_cap, ctrl, changed, cols, plan, btiles, strip_cstrips(L), parity);
+    return hipGetLastError();
+}
+
+// ===========================================================================
 // exact relaxation of the few cells that own a dead edge: one wave per cell
 // ===========================================================================
 // Lanes split the pull entries, apply the full liveness rule, and reduce their
