@@ -81,29 +81,24 @@ struct ttsweep_ctx {
     std::vector<std::array<int, 3>> special_offsets;   // device-axis offsets e: cell start - e owns a dead edge
     bool start_is_special = false;
     int max_box_cells = 0;                  // of the current solve
-    // STRIP: block -> (start, tile); shape 0: a workgroup is a tile of STRIP_NS strips,
-    // shape 1 (COOP): a workgroup is one strip-unit
-    int2 *d_worklist[2] = {nullptr, nullptr};
-    size_t worklist_cap[2] = {0, 0};
-    long long worklist_len[2] = {0, 0};
+    // STRIP: static work list, entry -> (start, unit), XCD-interleaved (build_worklist)
+    int2 *d_worklist = nullptr;
+    size_t worklist_cap = 0;
+    long long worklist_len = 0;
     // unit queues of a sparse pass (plan_pass_kernel -> sweep_units_kernel)
     int4 *d_unitq = nullptr;                // UNITQ_LISTS lists of unitq_cap entries
     size_t unitq_cap = 0;
     int *d_unitq_ctrl = nullptr;            // UNITQ_CTRL_WORDS (counts, cursors)
     int unitq_blocks = 0;                   // persistent grid: workgroups the device holds at once
-    std::vector<std::vector<int>> tile_order[2];    // per start: tile ids, nearest to the start first
+    std::vector<std::vector<int>> unit_order;       // per start: unit ids, nearest to the start first
     // Distance gate (see sweep_strip_kernel): radius of the first pass and cells it opens per
     // pass.  Defaults follow the star's reach: final values spread at about half the reach
     // per pass (measured, 818-offset star: 3.5 cells/pass gives the shortest solve).
     double gate_speed = 0.0;                // 0: no gate
     double gate_r0 = 0.0;
-    double coop_density = 0.5;              // fraction of all units relaxed in a pass below
-                                            // which the next pass uses one-unit workgroups
     int *d_tile_flags = nullptr;            // capacity_starts x 2 x tiles
     unsigned long long *d_work = nullptr;   // capacity_starts
     unsigned long long *h_work = nullptr;   // pinned
-    unsigned long long *h_units = nullptr;  // pinned, per pass slot
-    size_t h_units_cap = 0;
     int pass_index = 0;
 
     // per-solve pools (grown on demand, reused between solves)
@@ -194,7 +189,7 @@ static void make_layout_strip(ttsweep_ctx *ctx)
     L.lo[1] = std::max(r[1], 1);
     L.p[1] = ((L.n[1] + STRIP_TB - 1) / STRIP_TB) * STRIP_TB + 2 * L.lo[1];
     L.lo[2] = STRIP_CF;
-    L.p[2] = ((L.n[2] + STRIP_TC - 1) / STRIP_TC) * STRIP_TC + 2 * STRIP_CF;
+    L.p[2] = ((L.n[2] + STRIP_K - 1) / STRIP_K) * STRIP_K + 2 * STRIP_CF;
     L.s1 = L.p[2];
     L.s0 = (long long)L.p[1] * L.p[2];
     L.cells = L.s0 * L.p[0];
@@ -405,27 +400,27 @@ static int timed_event(ttsweep_ctx *ctx, hipEvent_t *out)
 // tile usually runs after the tiles between it and the start have finished their
 // update of this pass: fresh travel times then cross several tiles in ONE pass
 // instead of one tile per pass.  Correctness never depends on this order.
-static int build_worklist_shape(ttsweep_ctx *ctx, int nactive, int shape)
+static int build_worklist(ttsweep_ctx *ctx, int nactive)
 {
-    const int ntiles = shape == 0 ? strip_tiles(ctx->L) : strip_units(ctx->L);
-    constexpr int NX = 8;
+    const int nunits = strip_units(ctx->L);
+    constexpr int NX = UNITQ_LISTS;
     std::vector<std::vector<int2>> per_xcd(NX);
     if (nactive >= NX) {
         // XCD x serves starts x, x+8, ...; interleave them rank by rank
         for (int x = 0; x < NX; x++)
-            for (int k = 0; k < ntiles; k++)
+            for (int k = 0; k < nunits; k++)
                 for (int a = x; a < nactive; a += NX) {
                     const int s = ctx->h_active[a];
-                    per_xcd[x].push_back(make_int2(s, ctx->tile_order[shape][s][k]));
+                    per_xcd[x].push_back(make_int2(s, ctx->unit_order[s][k]));
                 }
     } else {
-        // start a owns XCDs a, a+nactive, ...; deal its tiles over them
+        // start a owns XCDs a, a+nactive, ...; deal its units over them
         for (int a = 0; a < nactive; a++) {
             const int s = ctx->h_active[a];
             std::vector<int> mine;
             for (int x = a; x < NX; x += nactive) mine.push_back(x);
-            for (int k = 0; k < ntiles; k++)
-                per_xcd[mine[k % mine.size()]].push_back(make_int2(s, ctx->tile_order[shape][s][k]));
+            for (int k = 0; k < nunits; k++)
+                per_xcd[mine[k % mine.size()]].push_back(make_int2(s, ctx->unit_order[s][k]));
         }
     }
     size_t longest = 0;
@@ -433,55 +428,46 @@ static int build_worklist_shape(ttsweep_ctx *ctx, int nactive, int shape)
     std::vector<int2> flat(longest * NX, make_int2(0, -1));
     for (int x = 0; x < NX; x++)
         for (size_t j = 0; j < per_xcd[x].size(); j++) flat[j * NX + x] = per_xcd[x][j];
-    if (flat.size() > ctx->worklist_cap[shape]) {
-        if (ctx->d_worklist[shape]) HIPCHK(hipFree(ctx->d_worklist[shape]));
-        ctx->d_worklist[shape] = nullptr;
-        HIPCHK(hipMalloc((void **)&ctx->d_worklist[shape], flat.size() * sizeof(int2)));
-        ctx->worklist_cap[shape] = flat.size();
+    if (flat.size() > ctx->worklist_cap) {
+        if (ctx->d_worklist) HIPCHK(hipFree(ctx->d_worklist));
+        ctx->d_worklist = nullptr;
+        HIPCHK(hipMalloc((void **)&ctx->d_worklist, flat.size() * sizeof(int2)));
+        ctx->worklist_cap = flat.size();
     }
-    HIPCHK(hipMemcpyAsync(ctx->d_worklist[shape], flat.data(), flat.size() * sizeof(int2),
+    HIPCHK(hipMemcpyAsync(ctx->d_worklist, flat.data(), flat.size() * sizeof(int2),
                           hipMemcpyHostToDevice, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));      // `flat` is a stack-lifetime buffer
-    ctx->worklist_len[shape] = (long long)flat.size();
-    if (shape == 1) {       // queues that can hold every unit of the list
-        const size_t cap = longest;
-        if (cap > ctx->unitq_cap) {
-            if (ctx->d_unitq) HIPCHK(hipFree(ctx->d_unitq));
-            ctx->d_unitq = nullptr;
-            HIPCHK(hipMalloc((void **)&ctx->d_unitq, cap * UNITQ_LISTS * sizeof(int4)));
-            ctx->unitq_cap = cap;
-        }
-        if (!ctx->d_unitq_ctrl) HIPCHK(hipMalloc((void **)&ctx->d_unitq_ctrl, UNITQ_CTRL_WORDS * sizeof(int)));
-        if (ctx->unitq_blocks == 0) {
-            hipDeviceProp_t prop;
-            HIPCHK(hipGetDeviceProperties(&prop, ctx->device));
-            const int wgs = 3 * std::max(prop.multiProcessorCount, 1);     // 3 workgroups (12 waves) per CU
-            ctx->unitq_blocks = ((wgs + UNITQ_LISTS - 1) / UNITQ_LISTS) * UNITQ_LISTS;
-        }
+    ctx->worklist_len = (long long)flat.size();
+    // queues that can hold every unit of the list
+    if (longest > ctx->unitq_cap) {
+        if (ctx->d_unitq) HIPCHK(hipFree(ctx->d_unitq));
+        ctx->d_unitq = nullptr;
+        HIPCHK(hipMalloc((void **)&ctx->d_unitq, longest * UNITQ_LISTS * sizeof(int4)));
+        ctx->unitq_cap = longest;
+    }
+    if (!ctx->d_unitq_ctrl) HIPCHK(hipMalloc((void **)&ctx->d_unitq_ctrl, UNITQ_CTRL_WORDS * sizeof(int)));
+    if (ctx->unitq_blocks == 0) {
+        hipDeviceProp_t prop;
+        HIPCHK(hipGetDeviceProperties(&prop, ctx->device));
+        const int wgs = 3 * std::max(prop.multiProcessorCount, 1);     // 3 workgroups (12 waves) per CU
+        ctx->unitq_blocks = ((wgs + UNITQ_LISTS - 1) / UNITQ_LISTS) * UNITQ_LISTS;
     }
     return 0;
 }
 
-static int build_worklist(ttsweep_ctx *ctx, int nactive)
-{
-    return (build_worklist_shape(ctx, nactive, 0) || build_worklist_shape(ctx, nactive, 1)) ? -1 : 0;
-}
-
-// Tiles of one start ordered by distance (tile centre to start point).
-static void order_tiles(const ttsweep_ctx *ctx, const StartDesc &sd, int shape, std::vector<int> &order)
+// Units of one start ordered by distance (unit centre to start point).
+static void order_units(const ttsweep_ctx *ctx, const StartDesc &sd, std::vector<int> &order)
 {
     const DevLayout &L = ctx->L;
-    const int btiles = (L.n[1] + STRIP_TB - 1) / STRIP_TB;
-    const int tc = shape == 0 ? STRIP_TC : STRIP_K;     // tile extent along c
-    const int ctiles = ((L.n[2] + STRIP_TC - 1) / STRIP_TC) * (STRIP_TC / tc);
-    const int ntiles = L.n[0] * btiles * ctiles;
-    std::vector<std::pair<long long, int>> key(ntiles);
-    for (int t = 0; t < ntiles; t++) {
-        const int ct = t % ctiles, bt = (t / ctiles) % btiles, a = t / (ctiles * btiles);
+    const int btiles = strip_btiles(L), cstrips = strip_cstrips(L);
+    const int nunits = strip_units(L);
+    std::vector<std::pair<long long, int>> key(nunits);
+    for (int t = 0; t < nunits; t++) {
+        const int cs = t % cstrips, bt = (t / cstrips) % btiles, a = t / (cstrips * btiles);
         const long long cb = std::min(bt * STRIP_TB + STRIP_TB / 2, L.n[1] - 1);
-        const long long cc = std::min(ct * tc + tc / 2, L.n[2] - 1);
+        const long long cc = std::min(cs * STRIP_K + STRIP_K / 2, L.n[2] - 1);
         const long long db = cb - sd.sb, dc = cc - sd.sc;
-        // runs of RUN consecutive planes (the planes a tile stages are then mostly L2 hits
+        // runs of RUN consecutive planes (the planes a unit stages are then mostly L2 hits
         // left by its predecessor), runs ordered by distance from the start
         constexpr int RUN = 8;
         const long long ca = (a / RUN) * RUN + RUN / 2;
@@ -489,8 +475,8 @@ static void order_tiles(const ttsweep_ctx *ctx, const StartDesc &sd, int shape, 
         key[t] = {(dq * dq + db * db + dc * dc) * 64 + a % RUN, t};
     }
     std::sort(key.begin(), key.end());
-    order.resize(ntiles);
-    for (int t = 0; t < ntiles; t++) order[t] = key[t].second;
+    order.resize(nunits);
+    for (int t = 0; t < nunits; t++) order[t] = key[t].second;
 }
 
 // Squared radius (cells) of the distance gate for the pass about to be launched.
@@ -501,30 +487,19 @@ static float gate_r2(const ttsweep_ctx *ctx)
     return (float)(r * r);
 }
 
-#ifdef TTSWEEP_PROFILE
-namespace ttsweep { void prof_dump(); }
-#endif
-
 // One full-grid pass for the active starts.
-static int launch_pass(ttsweep_ctx *ctx, int nactive, int *d_changed, int shape)
+static int launch_pass(ttsweep_ctx *ctx, int nactive, int *d_changed)
 {
     hipEvent_t e0, e1;
     if (ctx->timing && timed_event(ctx, &e0)) return -1;
     if (ctx->kernel == TTSWEEP_KERNEL_STRIP) {
-        if (shape == 1) {
-            HIPCHK(hipMemsetAsync(ctx->d_unitq_ctrl, 0, UNITQ_CTRL_WORDS * sizeof(int), ctx->stream));
-            HIPCHK(launch_plan_pass(ctx->L, ctx->d_starts, ctx->d_worklist[1], ctx->worklist_len[1],
-                                    d_changed, ctx->d_unitq, (int)ctx->unitq_cap, ctx->d_unitq_ctrl,
-                                    ctx->plan, ctx->pass_index & 1, gate_r2(ctx), ctx->stream));
-            HIPCHK(launch_sweep_units(ctx->L, ctx->d_v, ctx->d_starts, ctx->d_unitq,
-                                      (int)ctx->unitq_cap, ctx->d_unitq_ctrl, ctx->unitq_blocks,
-                                      d_changed, ctx->d_strip_cols, ctx->plan, ctx->pass_index & 1,
-                                      ctx->stream));
-        } else {
-            HIPCHK(launch_sweep_strip(ctx->L, ctx->d_v, ctx->d_starts, ctx->d_worklist[0],
-                                      ctx->worklist_len[0], false, d_changed, ctx->d_strip_cols,
-                                      ctx->plan, ctx->pass_index & 1, gate_r2(ctx), ctx->stream));
-        }
+        HIPCHK(hipMemsetAsync(ctx->d_unitq_ctrl, 0, UNITQ_CTRL_WORDS * sizeof(int), ctx->stream));
+        HIPCHK(launch_plan_pass(ctx->L, ctx->d_starts, ctx->d_worklist, ctx->worklist_len, d_changed,
+                                ctx->d_unitq, (int)ctx->unitq_cap, ctx->d_unitq_ctrl, ctx->plan,
+                                ctx->pass_index & 1, gate_r2(ctx), ctx->stream));
+        HIPCHK(launch_sweep_units(ctx->L, ctx->d_v, ctx->d_starts, ctx->d_unitq, (int)ctx->unitq_cap,
+                                  ctx->d_unitq_ctrl, ctx->unitq_blocks, d_changed, ctx->d_strip_cols,
+                                  ctx->plan, ctx->pass_index & 1, ctx->stream));
         HIPCHK(launch_sweep_special(ctx->L, ctx->d_v, ctx->d_starts, ctx->d_active, nactive,
                                     d_changed, ctx->d_cell_entries, ctx->n_cell_entries,
                                     ctx->max_box_cells, ctx->pass_index & 1, ctx->stream));
@@ -603,7 +578,6 @@ ttsweep_ctx *ttsweep_create(int device, int nx, int ny, int nz, const ttsweep_fs
     ctx->gate_r0 = ctx->radius + 1.0;
     if (const char *env = getenv("TTSWEEP_GATE_SPEED")) ctx->gate_speed = atof(env);    // experiments
     if (const char *env = getenv("TTSWEEP_GATE_R0")) ctx->gate_r0 = atof(env);
-    if (const char *env = getenv("TTSWEEP_COOP_DENSITY")) ctx->coop_density = atof(env);
     ctx->relax_per_sweep = ttsweep_relaxations_per_sweep(nx, ny, nz, fs, starstart, starstop);
     ctx->kernel = strip_supported(ctx) ? TTSWEEP_KERNEL_STRIP : TTSWEEP_KERNEL_CELL;
     if (const char *env = getenv("TTSWEEP_KERNEL")) {
@@ -647,13 +621,11 @@ void ttsweep_destroy(ttsweep_ctx *ctx)
     (void)hipFree(ctx->d_active);
     (void)hipFree(ctx->d_changed);
     (void)hipFree(ctx->d_tile_flags);
-    (void)hipFree(ctx->d_worklist[0]);
-    (void)hipFree(ctx->d_worklist[1]);
+    (void)hipFree(ctx->d_worklist);
     (void)hipFree(ctx->d_unitq);
     (void)hipFree(ctx->d_unitq_ctrl);
     (void)hipFree(ctx->d_work);
     if (ctx->h_work) (void)hipHostFree(ctx->h_work);
-    if (ctx->h_units) (void)hipHostFree(ctx->h_units);
     if (ctx->h_starts) (void)hipHostFree(ctx->h_starts);
     if (ctx->h_active) (void)hipHostFree(ctx->h_active);
     if (ctx->h_changed) (void)hipHostFree(ctx->h_changed);
@@ -773,10 +745,8 @@ int ttsweep_solve_device(ttsweep_ctx *ctx, int nstart, const ttsweep_start *star
         else HIPCHK(launch_pack(L, tt_dev[s], sd.T, INFINITY, ctx->stream));
         if (ctx->kernel == TTSWEEP_KERNEL_STRIP) {
             HIPCHK(launch_init_tile_flags(L, sd, /*from_box=*/!init, ctx->stream));
-            for (int shape = 0; shape < 2; shape++) {
-                if ((int)ctx->tile_order[shape].size() < nstart) ctx->tile_order[shape].resize(nstart);
-                order_tiles(ctx, sd, shape, ctx->tile_order[shape][s]);
-            }
+            if ((int)ctx->unit_order.size() < nstart) ctx->unit_order.resize(nstart);
+            order_units(ctx, sd, ctx->unit_order[s]);
         }
         ctx->h_active[s] = s;
     }
@@ -795,20 +765,8 @@ int ttsweep_solve_device(ttsweep_ctx *ctx, int nstart, const ttsweep_start *star
     // that was launched speculatively for it finds all its units inactive.
     std::vector<int> sweeps(nstart, 0);
     const bool trace = getenv("TTSWEEP_TRACE") != nullptr;
-    unsigned long long trace_prev = 0, trace_prev_wg = 0, trace_prev_un = 0;
+    unsigned long long trace_prev = 0, trace_prev_un = 0;
     std::vector<int> snapshot[PASS_SLOTS];      // active starts of each pass in flight
-    // workgroup shape of the next pass: one-unit (COOP) workgroups while only a thin front is
-    // active, tiles of STRIP_NS units when the pass fills the machine.  The number of units
-    // relaxed per pass is read back with the "changed" words (so it lags one pass).
-    int shape = 1;                              // the first passes only touch the start's surroundings
-    unsigned long long units_prev = 0;
-    if (ctx->h_units_cap < (size_t)PASS_SLOTS * 3 * nstart) {
-        if (ctx->h_units) HIPCHK(hipHostFree(ctx->h_units));
-        ctx->h_units = nullptr;
-        HIPCHK(hipHostMalloc((void **)&ctx->h_units, (size_t)PASS_SLOTS * 3 * nstart * sizeof(unsigned long long)));
-        ctx->h_units_cap = (size_t)PASS_SLOTS * 3 * nstart;
-    }
-    unsigned long long *h_units = ctx->h_units;
     int nactive = nstart, launched = 0, processed = 0;
     bool anychange_ever = false;
     auto t_pass = std::chrono::steady_clock::now();
@@ -817,13 +775,9 @@ int ttsweep_solve_device(ttsweep_ctx *ctx, int nstart, const ttsweep_start *star
             const int slot = launched % PASS_SLOTS;
             int *dch = ctx->d_changed + (size_t)slot * nstart;
             HIPCHK(hipMemsetAsync(dch, 0, nstart * sizeof(int), ctx->stream));
-            if (launch_pass(ctx, nactive, dch, shape)) return -1;
+            if (launch_pass(ctx, nactive, dch)) return -1;
             HIPCHK(hipMemcpyAsync(ctx->h_changed + (size_t)slot * nstart, dch, nstart * sizeof(int),
                                   hipMemcpyDeviceToHost, ctx->stream));
-            if (ctx->kernel == TTSWEEP_KERNEL_STRIP)        // units relaxed so far (shape choice)
-                HIPCHK(hipMemcpyAsync(h_units + (size_t)slot * 3 * nstart, ctx->d_work,
-                                      3 * nstart * sizeof(unsigned long long),
-                                      hipMemcpyDeviceToHost, ctx->stream));
             HIPCHK(hipEventRecord(ctx->ev_flags[slot], ctx->stream));
             snapshot[slot].assign(ctx->h_active, ctx->h_active + nactive);
             launched++;
@@ -833,32 +787,22 @@ int ttsweep_solve_device(ttsweep_ctx *ctx, int nstart, const ttsweep_start *star
         const int slot = processed % PASS_SLOTS;
         HIPCHK(hipEventSynchronize(ctx->ev_flags[slot]));
         const int *hch = ctx->h_changed + (size_t)slot * nstart;
-        if (ctx->kernel == TTSWEEP_KERNEL_STRIP) {
-            unsigned long long units = 0;
-            for (int s = 0; s < nstart; s++) units += h_units[(size_t)slot * 3 * nstart + 3 * s + 2];
-            const double all_units = (double)snapshot[slot].size() * strip_units(L);
-            shape = (double)(units - units_prev) < ctx->coop_density * all_units ? 1 : 0;
-            units_prev = units;
-        }
         if (trace) {    // TTSWEEP_TRACE=1: per-pass activity on stderr (serialises the passes)
             HIPCHK(hipStreamSynchronize(ctx->stream));
             HIPCHK(hipMemcpy(ctx->h_work, ctx->d_work, 3 * nstart * sizeof(unsigned long long),
                              hipMemcpyDeviceToHost));
-            unsigned long long tot = 0, wgs = 0, un = 0;
-            for (int s = 0; s < nstart; s++) {
-                tot += ctx->h_work[3 * s]; wgs += ctx->h_work[3 * s + 1]; un += ctx->h_work[3 * s + 2];
-            }
+            unsigned long long tot = 0, un = 0;
+            for (int s = 0; s < nstart; s++) { tot += ctx->h_work[3 * s]; un += ctx->h_work[3 * s + 2]; }
             const double us = std::chrono::duration<double, std::micro>(
                                   std::chrono::steady_clock::now() - t_pass).count();
             t_pass = std::chrono::steady_clock::now();
             fprintf(stderr, "ttsweep pass %d: %d active starts, %.3f full-sweep equivalents relaxed, "
-                    "%llu workgroups ran, %llu units, %.0f us, next shape %d\n", processed + 1, (int)snapshot[slot].size(),
+                    "%llu units, %.0f us\n", processed + 1, (int)snapshot[slot].size(),
                     (double)(tot - trace_prev) / (double)ctx->stats.cells
                         / (double)std::max<size_t>(ctx->pull.size(), 1),
-                    wgs - trace_prev_wg, un - trace_prev_un, us, shape);
+                    un - trace_prev_un, us);
             trace_prev = tot;
             trace_prev_un = un;
-            trace_prev_wg = wgs;
         }
         bool dropped = false;
         for (int s : snapshot[slot]) {
@@ -895,9 +839,6 @@ int ttsweep_solve_device(ttsweep_ctx *ctx, int nstart, const ttsweep_start *star
     HIPCHK(hipEventRecord(ctx->ev_solve1, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
 
-#ifdef TTSWEEP_PROFILE
-    prof_dump();
-#endif
     float ms = 0;
     HIPCHK(hipEventElapsedTime(&ms, ctx->ev_solve0, ctx->ev_solve1));
     ctx->stats.solve_ms = ms;

@@ -71,15 +71,13 @@ struct StartDesc {
 // STRIP kernel geometry (compile-time)
 // ---------------------------------------------------------------------------
 constexpr int STRIP_K = 16;                         // cells per thread along c
-constexpr int STRIP_NS = 4;                         // strips (= waves) per workgroup
+constexpr int STRIP_NS = 4;                         // waves per workgroup
 constexpr int STRIP_TB = 64;                        // lanes along b
 constexpr int STRIP_CF = 8;                         // halo in front of a strip window (>= max|dc|, multiple of 4)
 constexpr int STRIP_W = STRIP_K + 2 * STRIP_CF;     // neighbour window per (cell strip, column)
-constexpr int STRIP_TC = STRIP_K * STRIP_NS;        // tile extent along c
-constexpr int STRIP_PWV = STRIP_TC + 2 * STRIP_CF;  // valid floats per slab row
-// slab row pitch: PW/4 must be odd so that 16 lanes reading float4 at a stride
-// of one row hit 64 distinct banks (MI355X_MICROARCH.md, LDS ds_read_b128)
-constexpr int STRIP_PW = STRIP_PWV + (((STRIP_PWV / 4) % 2 == 0) ? 4 : 0);
+// slab row pitch: STRIP_W valid floats; PW/4 must be odd so that 16 lanes reading float4 at a
+// stride of one row hit 64 distinct banks (MI355X_MICROARCH.md, LDS ds_read_b128)
+constexpr int STRIP_PW = STRIP_W + (((STRIP_W / 4) % 2 == 0) ? 4 : 0);
 constexpr int STRIP_MAX_RA = 7;                     // plane offsets handled: |da| <= 7
 
 // One (da, db) column of the pull star: all offsets that differ only in dc.
@@ -100,6 +98,11 @@ struct StripPlan {
     // shares of nearly equal cost
     unsigned char wsplit[2 * STRIP_MAX_RA + 1][STRIP_NS + 1];
 };
+
+// Unit grid of one start: planes a x lane tiles along b x strips along c.
+__host__ __device__ inline int strip_btiles(const DevLayout &L) { return (L.n[1] + STRIP_TB - 1) / STRIP_TB; }
+__host__ __device__ inline int strip_cstrips(const DevLayout &L) { return (L.n[2] + STRIP_K - 1) / STRIP_K; }
+__host__ __device__ inline int strip_units(const DevLayout &L) { return L.n[0] * strip_btiles(L) * strip_cstrips(L); }
 
 // Unit queues of one pass (sweep_units_kernel): 8 lists, one per XCD, filled by
 // plan_pass_kernel.  ctrl[0..7] = entries in list x, ctrl[8..15] = next entry to hand out.

@@ -36,28 +36,13 @@ hipError_t launch_validate(const DevLayout &L, const float *v, const float *T, l
 // (StartDesc::box_*) are left untouched; launch_sweep_special relaxes exactly
 // those cells with the full liveness rule.
 //
-// Activity tracking: a tile is relaxed in pass k only if a tile it reads from
-// (itself, its 8 in-plane neighbours, over all plane offsets) improved in pass
-// k-1; `parity` = k & 1 selects which half of StartDesc::tile_flags is written.
-size_t strip_lds_bytes(const StripPlan &plan, int nb, bool coop);
-int strip_tiles(const DevLayout &L);            // workgroup tiles per start
-int strip_units(const DevLayout &L);            // activity units (one per wave) per start
-// work[b] = (start index, tile id) of block b, tile id = (a*btiles + bt)*ctiles + ct,
-// or tile id < 0 for a padding entry.  coop: one unit per workgroup (tile id = unit id,
-// ctiles = strips along c), its waves sharing the star's columns - for sparse passes.
-hipError_t launch_sweep_strip(const DevLayout &L, const float *v, const StartDesc *starts,
-                              const int2 *work, long long nblocks, bool coop, int *changed,
-                              const StripCol *cols, const StripPlan &plan, int parity,
-                              float gate_r2, hipStream_t st);
-hipError_t launch_sweep_special(const DevLayout &L, const float *v, const StartDesc *starts,
-                                const int *active, int nactive, int *changed,
-                                const CellEntry *entries, int nentries, int max_box_cells,
-                                int parity, hipStream_t st);
-// ---- unit queues (sparse passes) --------------------------------------------
-// plan_pass: one thread per entry of the static work list `work` (unit ids, XCD-interleaved:
-// entry i belongs to XCD i % 8).  Decides which units are due in this pass (activity flags of
-// the previous pass, distance gate, held-back plane bits) and appends (start, unit, planes)
-// to the queue of the unit's XCD; clears the unit's flag word of this pass.
+// A pass = launch_plan_pass + launch_sweep_units (+ launch_sweep_special).  `parity` =
+// pass index & 1 selects which half of StartDesc::tile_flags the pass writes.
+// plan_pass: one thread per entry of the static work list `work`: work[i] = (start index,
+// unit id = (a*btiles + bt)*cstrips + cs) or unit id < 0 for padding; entry i belongs to
+// XCD i % 8.  Decides which units are due in this pass (activity flags of the previous
+// pass, distance gate, held-back plane bits), appends (start, unit, planes) to the queue of
+// the unit's XCD and clears the unit's flag word of this pass.
 // sweep_units: a persistent grid (`nblocks` workgroups) drains the queues, own XCD first.
 size_t units_lds_bytes(const StripPlan &plan, int nb);
 hipError_t launch_plan_pass(const DevLayout &L, const StartDesc *starts, const int2 *work,
@@ -67,7 +52,12 @@ hipError_t launch_sweep_units(const DevLayout &L, const float *v, const StartDes
                               const int4 *lists, int list_cap, int *ctrl, int nblocks,
                               int *changed, const StripCol *cols, const StripPlan &plan,
                               int parity, hipStream_t st);
-// flags[1][*] = all_active ? 1 : (tile == start's tile); flags[0][*] = 0
+hipError_t launch_sweep_special(const DevLayout &L, const float *v, const StartDesc *starts,
+                                const int *active, int nactive, int *changed,
+                                const CellEntry *entries, int nentries, int max_box_cells,
+                                int parity, hipStream_t st);
+// First activity flags of a start: from_box = false: only the start's unit is a source;
+// from_box = true: every unit that holds a finite travel time is one.
 hipError_t launch_init_tile_flags(const DevLayout &L, const StartDesc &sd, bool from_box,
                                   hipStream_t st);
 

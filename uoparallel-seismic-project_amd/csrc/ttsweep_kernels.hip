@@ -253,23 +253,25 @@ hipError_t launch_validate(const DevLayout &L, const float *v, const float *T, l
 // ===========================================================================
 //
 // Work decomposition (device axes a, b, c; c is stride-1):
-//   workgroup = one plane a x 64 cells along b x STRIP_TC cells along c
-//   wave      = 64 lanes along b, one strip of STRIP_K consecutive c cells per lane
-// Each lane keeps acc[K] (best travel time so far) and its own velocities (as
-// register pairs) in registers.  For every plane offset da the workgroup stages
-// the neighbour plane's (64 + 2 rb) x (TC + 16) window of v and T into LDS once;
-// then for every (da, db) column of the star a lane reads ONE register window of
-// K + 16 neighbour values (up to 8 ds_read_b128 per array, conflict-free by the
-// odd row pitch) and relaxes all offsets dc of that column against it: each
-// loaded value is reused for up to 15 offsets, which is what keeps the kernel
-// VALU-bound instead of LDS-bound.
+//   unit      = one plane a x 64 cells along b x one strip of STRIP_K cells along c:
+//               what one workgroup relaxes at a time, and the granule of activity tracking
+//   lane      = one b row of the unit: K consecutive c cells, held in registers
+//   wave      = a share of the star's (da, db) columns (the four waves of the workgroup
+//               min-combine their partial results at the end)
+// Each lane keeps acc[K] (best travel time so far) and its own velocities (as register
+// pairs) in registers.  For every plane offset da the workgroup stages the neighbour
+// plane's (64 + 2 rb) x (K + 16) window of v and T into LDS once; then for every (da, db)
+// column of the star a lane reads ONE register window of K + 16 neighbour values (up to
+// 8 ds_read_b128 per array, conflict-free by the odd row pitch) and relaxes all offsets
+// dc of that column against it: each loaded value is reused for up to 15 offsets, which
+// is what keeps the kernel VALU-bound instead of LDS-bound.
 //
 // The relaxation is branch-free: there are no bounds tests (halo cells hold
 // +INF / 0) and no liveness tests.  The few cells that own a dead edge (inside
 // StartDesc::box) are computed but not stored; sweep_special_kernel owns them.
 
-// Workgroup-wide reductions go through the first words of the dynamic LDS region (no
-// static __shared__ object: it would shift the 16-byte alignment of the dynamic base).
+// The first words of the dynamic LDS region carry workgroup-wide scalars (no static
+// __shared__ object: it would shift the 16-byte alignment of the dynamic base).
 constexpr int STRIP_LDS_HEAD = 16;      // floats reserved in front of the slabs
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
@@ -308,20 +310,6 @@ __device__ __forceinline__ void pin_col(ColRegs &r)
 // Activity flag bits of a unit (tile_flags): something improved at all / within the
 // first / the last CF-1 cells of the strip (the only cells a neighbouring strip reads).
 enum : int { FLAG_ANY = 1, FLAG_LO = 2, FLAG_HI = 4 };
-
-// Workgroup-wide OR of one word per wave.
-template <int NS>
-__device__ __forceinline__ unsigned block_or_mask(unsigned m, float *smem, int wave, int lane)
-{
-    unsigned *words = reinterpret_cast<unsigned *>(smem);
-    __syncthreads();
-    if (lane == 0) words[wave] = m;
-    __syncthreads();
-    unsigned any = 0;
-#pragma unroll
-    for (int w = 0; w < NS; w++) any |= words[w];
-    return any;
-}
 
 // Relax all offsets dc of one (da, db) column: load the neighbour window from LDS into
 // registers once, then fold every present offset into acc.
@@ -415,288 +403,6 @@ __device__ __forceinline__ void relax_column(const ColRegs &cur, const float *pv
     }
 }
 
-// K cells per lane (strip length).  (A K = 8 instance was measured: finer activity units,
-// more overhead per relaxation, same time to solution; only K = 16 is built.)
-//
-// Two workgroup shapes share this body:
-//   COOP = false  workgroup = STRIP_TC / K strips of one tile, one wave per strip (unit).
-//                 Least staging per cell; the shape for passes that fill the machine.
-//   COOP = true   workgroup = ONE unit; its waves split the star's columns among
-//                 themselves and min-combine their partial results through LDS.  Four
-//                 times shorter critical path per unit; the shape for passes in which only
-//                 a thin front is active and the pass time is the time of one workgroup.
-#ifdef TTSWEEP_PROFILE
-__device__ unsigned long long g_prof[8];
-#define PROF_T(x) const long long x = clock64()
-#define PROF_ADD(i, v) do { if (lane == 0) atomicAdd(&g_prof[i], (unsigned long long)(v)); } while (0)
-#else
-#define PROF_T(x)
-#define PROF_ADD(i, v)
-#endif
-
-template <int K, bool COOP>
-__global__ void __launch_bounds__(STRIP_TB *(STRIP_TC / K), 3)
-sweep_strip_kernel(DevLayout L, const float *__restrict__ v,
-                   const StartDesc *__restrict__ starts, const int2 *__restrict__ work,
-                   int *__restrict__ changed, const StripCol *__restrict__ cols,
-                   StripPlan plan, int btiles, int ctiles, int parity, float gate_r2)
-{
-    static_assert(STRIP_TC % K == 0 && K % 4 == 0, "strips must tile the workgroup tile");
-    constexpr int NS = STRIP_TC / K;            // waves per workgroup
-    constexpr int NT = STRIP_TB * NS;
-    constexpr int TC = COOP ? K : STRIP_TC;     // tile extent along c
-    constexpr int PWV = TC + 2 * STRIP_CF;      // valid floats per slab row
-    constexpr int PW = PWV + (((PWV / 4) % 2 == 0) ? 4 : 0);   // row pitch, PW/4 odd
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-
-    // Block -> (start, tile) through a host-built work list (see build_worklist in
-    // ttsweep_api.cpp): entries are ordered so that consecutive blocks of one XCD
-    // (blocks b, b+8, b+16, ... share an XCD and its L2) walk the tiles of "their"
-    // starts from the start point outwards.
-    PROF_T(t_begin);
-    const int2 item = work[blockIdx.x];
-    const int s = item.x;
-    if (item.y < 0) return;                 // padding entry
-    int tile_id = item.y;
-    const int ct = tile_id % ctiles;  tile_id /= ctiles;
-    const int bt = tile_id % btiles;  tile_id /= btiles;
-    const int a = tile_id;
-
-    const int lane = threadIdx.x;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.y);   // wave-uniform: keep it scalar
-    const int strip = COOP ? 0 : wave;          // which strip of the tile this wave owns
-    const int tid = wave * STRIP_TB + lane;
-    const int b0 = bt * STRIP_TB;
-    const int c0 = ct * TC;
-    const int rb = plan.rb;
-    const int tb_eff = min(STRIP_TB, L.n[1]);       // lanes that can own a cell
-    const int rows = tb_eff + 2 * rb;
-    const int lane_r = min(lane, tb_eff - 1);       // idle lanes mirror a valid row
-
-    const StartDesc sd = starts[s];
-    float *__restrict__ T = sd.T;
-
-    // ---- activity test, per wave and per neighbour plane.  A "unit" is what one wave
-    // relaxes: plane a x (up to) 64 cells along b x one strip of K cells along c.  The
-    // offsets with plane offset da have to be relaxed in this pass only if a unit they
-    // read from (plane a+da, +-1 lane tile, +-1 strip) improved in the previous pass:
-    // everything else was already relaxed against unchanged values.
-    const int cstrips = COOP ? ctiles : ctiles * NS;
-    const int nunits = L.n[0] * btiles * cstrips;
-    const int my_cs = COOP ? ct : ct * NS + strip;
-    const int my_unit = (a * btiles + bt) * cstrips + my_cs;
-    int *__restrict__ cur_flags = sd.tile_flags + parity * nunits;
-    unsigned my_planes = 0;     // bit ia: plane offset da = ia - ra is due for this wave
-    {
-        const int *__restrict__ prev_flags = sd.tile_flags + (1 - parity) * nunits;
-        for (int idx = lane; idx < 9 * (2 * plan.ra + 1); idx += 64) {
-            const int ia = idx / 9;
-            const int r = idx % 9;
-            const int na = a + ia - plan.ra, nb = bt + r / 3 - 1, nc = my_cs + r % 3 - 1;
-            // a neighbouring strip matters only if the change was within reach (< CF
-            // cells) of the shared border: FLAG_LO / FLAG_HI say which end changed
-            const int need = (r % 3 == 0) ? FLAG_HI : (r % 3 == 2) ? FLAG_LO : FLAG_ANY;
-            if (na >= 0 && na < L.n[0] && nb >= 0 && nb < btiles && nc >= 0 && nc < cstrips
-                && (prev_flags[(na * btiles + nb) * cstrips + nc] & need))
-                my_planes |= 1u << ia;
-        }
-#pragma unroll
-        for (int w = 32; w >= 1; w >>= 1) my_planes |= __shfl_xor(my_planes, w);
-    }
-    // ---- distance gate.  Far from the start the first values to arrive (over long edges)
-    // are poor and get refined pass after pass; relaxing those units early is wasted work.
-    // A unit is therefore held back until the gate radius (it grows by a fixed number of
-    // cells per pass) reaches it.  What it has to relax is remembered in pend[] (plane
-    // bits accumulate across passes), so holding a unit back never loses an update, and a
-    // start with anything pending is not reported as converged.
-    unsigned *__restrict__ pend = reinterpret_cast<unsigned *>(sd.tile_flags + 2 * nunits);
-    unsigned held;
-    {
-        const int cb0 = c0 + strip * K;
-        const float da_ = (float)abs(a - sd.sa);
-        const float db_ = (float)max(max(b0 - sd.sb, sd.sb - (b0 + tb_eff - 1)), 0);
-        const float dc_ = (float)max(max(cb0 - sd.sc, sd.sc - (cb0 + K - 1)), 0);
-        // (the gate is for solves that grow from one source unit; a box that arrives with
-        // many finite units, e.g. an already converged one, is relaxed ungated)
-        const bool gated = sd.tile_flags[3 * nunits] == 1;
-        const bool open = !gated || da_ * da_ + db_ * db_ + dc_ * dc_ <= gate_r2;
-        held = pend[my_unit];       // COOP: every wave reads it; it is cleared in the epilogue
-        if (!open && lane == 0 && (!COOP || wave == 0)) {
-            if (my_planes & ~held) pend[my_unit] = held | my_planes;
-            if (held | my_planes) atomicOr(&changed[s], 1);        // work is waiting
-        }
-        my_planes = open ? (my_planes | held) : 0u;
-    }
-    const bool wave_active = my_planes != 0;
-    const unsigned wg_planes = COOP ? my_planes : block_or_mask<NS>(my_planes, smem, wave, lane);
-    if (wg_planes == 0) {
-        if (lane == 0 && (!COOP || wave == 0)) cur_flags[my_unit] = 0;
-        return;
-    }
-
-    if (tid == 0) atomicAdd(sd.work + 1, 1ull);     // workgroups that had to run (statistics)
-    PROF_T(t_active);
-#ifdef TTSWEEP_PROFILE
-    long long p_wait = 0, p_stage = 0, p_comp = 0;
-#endif
-
-    float *sv = smem + STRIP_LDS_HEAD;
-    float *sT = sv + rows * PW;
-
-    // own cells: (a, b0 + lane, c0 + strip*K + q)
-    const long long own = (long long)(a + L.lo[0]) * L.s0 + (long long)(b0 + lane_r + L.lo[1]) * L.s1
-                        + (c0 + strip * K + L.lo[2]);
-    float acc[K];
-    f32x2 vce[K / 2];       // own velocities as register pairs (0,1),(2,3),...
-    f32x2 vco[K / 2 - 1];   // ... and as pairs (1,2),(3,4),... for the odd offsets
-#pragma unroll
-    for (int j = 0; j < K / 4; j++) {
-        const float4 x = *reinterpret_cast<const float4 *>(v + own + 4 * j);
-        const float4 y = *reinterpret_cast<const float4 *>(T + own + 4 * j);
-        vce[2 * j] = f32x2{x.x, x.y}; vce[2 * j + 1] = f32x2{x.z, x.w};
-        acc[4 * j + 0] = y.x; acc[4 * j + 1] = y.y; acc[4 * j + 2] = y.z; acc[4 * j + 3] = y.w;
-    }
-#pragma unroll
-    for (int p = 0; p < K / 2 - 1; p++) vco[p] = f32x2{vce[p].y, vce[p + 1].x};
-
-    constexpr int F4_PER_ROW = PWV / 4;
-    const int nf4 = rows * F4_PER_ROW;
-
-    for (int ia = 0; ia <= 2 * plan.ra; ia++) {
-        const int cbeg = plan.first[ia], cend = plan.first[ia + 1];
-        if (cbeg == cend || !((wg_planes >> ia) & 1u)) continue;
-        const int da = ia - plan.ra;
-
-        // ---- stage plane a+da: rows b0-rb .. b0+63+rb, columns c0-CF .. c0+TC+CF-1
-        const long long src = (long long)(a + da + L.lo[0]) * L.s0
-                            + (long long)(b0 - rb + L.lo[1]) * L.s1 + (c0 - STRIP_CF + L.lo[2]);
-        PROF_T(t0);
-        __syncthreads();            // everybody is done reading the previous slab
-        PROF_T(t1);
-        for (int f = tid; f < nf4; f += NT) {
-            const int r = f / F4_PER_ROW;
-            const int c4 = f - r * F4_PER_ROW;
-            const long long g = src + (long long)r * L.s1 + 4 * c4;
-            const float4 xv = *reinterpret_cast<const float4 *>(v + g);
-            const float4 xt = *reinterpret_cast<const float4 *>(T + g);
-            *reinterpret_cast<float4 *>(sv + r * PW + 4 * c4) = xv;
-            *reinterpret_cast<float4 *>(sT + r * PW + 4 * c4) = xt;
-        }
-        __syncthreads();
-        PROF_T(t2);
-#ifdef TTSWEEP_PROFILE
-        p_wait += t1 - t0; p_stage += t2 - t1;
-#endif
-
-        // ---- relax every column of this plane offset.  The column descriptor lives
-        // in SGPRs; the NEXT column's descriptor is requested before this column's
-        // arithmetic so its scalar-load latency is hidden.
-        if (!((my_planes >> ia) & 1u)) continue;    // this wave only helps staging
-        constexpr int CSTEP = COOP ? NS : 1;        // COOP: the waves take the columns in turn
-        const int cfirst = COOP ? cbeg + wave : cbeg;
-        if (cfirst >= cend) continue;
-        ColRegs cur = load_col(cols, cfirst);
-        for (int ci = cfirst; ci < cend; ci += CSTEP) {
-            pin_col(cur);
-            const ColRegs nxt = load_col(cols, min(ci + CSTEP, cend - 1));
-            const float *pv = sv + (lane_r + rb + cur.rowoff) * PW + strip * K;
-            const float *pt = pv + rows * PW;
-            // columns whose dc set is one of the shipped stars' get a straight-line
-            // routine (compile-time set: no per-offset branches, only the window chunks
-            // that set needs); any other set takes the generic bit-test routine
-            switch (cur.mask) {
-#define STRIP_MASK_CASE(m) case m: relax_column<K, m>(cur, pv, pt, vce, vco, acc); break;
-#include "strip_masks.inc"
-#undef STRIP_MASK_CASE
-            default: relax_column<K, 0u>(cur, pv, pt, vce, vco, acc); break;
-            }
-            cur = nxt;
-        }
-#ifdef TTSWEEP_PROFILE
-        p_comp += clock64() - t2;
-#endif
-    }
-    PROF_T(t_loop);
-
-    if (COOP) {
-        // min-combine the waves' partial results: [wave][cell][lane] floats in LDS
-        float *comb = smem + STRIP_LDS_HEAD;
-        __syncthreads();                // the last slab is no longer read
-#pragma unroll
-        for (int q = 0; q < K; q++) comb[(wave * K + q) * STRIP_TB + lane] = acc[q];
-        __syncthreads();
-        if (wave != 0) return;
-#pragma unroll
-        for (int w = 1; w < NS; w++)
-#pragma unroll
-            for (int q = 0; q < K; q++) acc[q] = fminf(acc[q], comb[(w * K + q) * STRIP_TB + lane]);
-    }
-
-    // ---- epilogue: store improved cells that lie inside the grid and outside the
-    // dead-edge box of this start
-    const int b = b0 + lane;
-    const int cbase = c0 + strip * K;
-    const bool row_ok = lane < tb_eff && b < L.n[1];
-    const bool in_box_ab = a >= sd.box_lo[0] && a <= sd.box_hi[0] && b >= sd.box_lo[1] && b <= sd.box_hi[1];
-    int improved = 0;           // FLAG_* bits
-    if (wave_active) {
-#pragma unroll
-        for (int q = 0; q < K; q++) {
-            const int c = cbase + q;
-            const bool special = in_box_ab && c >= sd.box_lo[2] && c <= sd.box_hi[2];
-            if (row_ok && c < L.n[2] && !special && acc[q] < T[own + q]) {
-                T[own + q] = acc[q];
-                improved |= FLAG_ANY | (q < STRIP_CF - 1 ? FLAG_LO : 0) | (q > K - STRIP_CF ? FLAG_HI : 0);
-            }
-        }
-    }
-#pragma unroll
-    for (int w = 32; w >= 1; w >>= 1) improved |= __shfl_xor(improved, w);
-    const bool any = improved != 0;
-    if (lane == 0) {
-        cur_flags[my_unit] = improved;
-        if (any) atomicOr(&changed[s], 1);
-        if (wave_active) {
-            if (held) pend[my_unit] = 0;        // what was held back has now been relaxed
-            const int wb = min(tb_eff, L.n[1] - b0), wc = max(min(K, L.n[2] - cbase), 0);
-            int nent = 0;
-            for (int ia = 0; ia <= 2 * plan.ra; ia++)
-                if ((my_planes >> ia) & 1u) nent += plan.nent[ia];
-            atomicAdd(sd.work, (unsigned long long)(wb * wc) * (unsigned long long)nent);
-            atomicAdd(sd.work + 2, 1ull);       // units relaxed (drives the choice of workgroup shape)
-        }
-    }
-#ifdef TTSWEEP_PROFILE
-    {
-        const long long t_end = clock64();
-        PROF_ADD(0, t_active - t_begin); PROF_ADD(1, p_wait); PROF_ADD(2, p_stage); PROF_ADD(3, p_comp);
-        PROF_ADD(4, t_end - t_loop); PROF_ADD(5, t_end - t_begin); PROF_ADD(6, 1);
-    }
-#endif
-}
-
-#ifdef TTSWEEP_PROFILE
-void prof_dump()
-{
-    unsigned long long h[8] = {};
-    (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(g_prof), sizeof(h));
-    const double n = (double)std::max<unsigned long long>(h[6], 1);
-    fprintf(stderr, "prof (wave 0 of %llu active WGs, cycles/WG): prologue %.0f  wait %.0f  stage %.0f  compute %.0f  epilogue %.0f  total %.0f\n",
-            h[6], h[0] / n, h[1] / n, h[2] / n, h[3] / n, h[4] / n, h[5] / n);
-    unsigned long long z[8] = {};
-    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_prof), z, sizeof(z));
-}
-#endif
-
-int strip_tiles(const DevLayout &L)
-{
-    return L.n[0] * ((L.n[1] + STRIP_TB - 1) / STRIP_TB) * ((L.n[2] + STRIP_TC - 1) / STRIP_TC);
-}
-
-int strip_units(const DevLayout &L) { return strip_tiles(L) * STRIP_NS; }
-
-static int strip_cstrips(const DevLayout &L) { return ((L.n[2] + STRIP_TC - 1) / STRIP_TC) * STRIP_NS; }
-
 __global__ void __launch_bounds__(256)
 init_tile_flags_kernel(int *__restrict__ flags, int nunits, int start_unit)
 {
@@ -737,11 +443,8 @@ init_tile_flags_box_kernel(DevLayout L, const float *__restrict__ T, int *__rest
 hipError_t launch_init_tile_flags(const DevLayout &L, const StartDesc &sd, bool from_box,
                                   hipStream_t st)
 {
-    constexpr int k = STRIP_K;
-    const int btiles = (L.n[1] + STRIP_TB - 1) / STRIP_TB;
-    const int ctiles = (L.n[2] + STRIP_TC - 1) / STRIP_TC;
-    const int cstrips = ctiles * (STRIP_TC / k);
-    const int nunits = L.n[0] * btiles * cstrips;
+    const int btiles = strip_btiles(L), cstrips = strip_cstrips(L);
+    const int nunits = strip_units(L);
     if (from_box) {
         hipError_t e = hipMemsetAsync(sd.tile_flags + 3 * (size_t)nunits, 0, sizeof(int), st);
         if (e != hipSuccess) return e;
@@ -749,62 +452,33 @@ hipError_t launch_init_tile_flags(const DevLayout &L, const StartDesc &sd, bool 
                            sd.tile_flags, nunits, btiles, cstrips);
         return hipGetLastError();
     }
-    const int start_unit = (sd.sa * btiles + sd.sb / STRIP_TB) * cstrips + sd.sc / k;
+    const int start_unit = (sd.sa * btiles + sd.sb / STRIP_TB) * cstrips + sd.sc / STRIP_K;
     hipLaunchKernelGGL(init_tile_flags_kernel, dim3((nunits + 255) / 256), dim3(256), 0, st,
                        sd.tile_flags, nunits, start_unit);
     return hipGetLastError();
 }
 
-size_t strip_lds_bytes(const StripPlan &plan, int nb, bool coop)
-{
-    const int pwv = (coop ? STRIP_K : STRIP_TC) + 2 * STRIP_CF;
-    const int pw = pwv + (((pwv / 4) % 2 == 0) ? 4 : 0);
-    size_t floats = (size_t)2 * (std::min(STRIP_TB, nb) + 2 * plan.rb) * pw;
-    if (coop) floats = std::max(floats, (size_t)STRIP_TC * STRIP_TB);      // combine buffer
-    return (floats + STRIP_LDS_HEAD) * sizeof(float);
-}
-
-template <int K, bool COOP>
-static hipError_t launch_strip_k(const DevLayout &L, const float *v, const StartDesc *starts,
-                                 const int2 *work, long long nblocks, int *changed,
-                                 const StripCol *cols, const StripPlan &plan, int parity,
-                                 float gate_r2, hipStream_t st)
-{
-    const int btiles = (L.n[1] + STRIP_TB - 1) / STRIP_TB;
-    const int ctiles = COOP ? strip_cstrips(L) : (L.n[2] + STRIP_TC - 1) / STRIP_TC;
-    auto kern = sweep_strip_kernel<K, COOP>;
-    const size_t lds = strip_lds_bytes(plan, L.n[1], COOP);
-    if (lds > 48 * 1024) {      // above the default dynamic-LDS limit
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return e;
-    }
-    hipLaunchKernelGGL(kern, dim3((unsigned)nblocks), dim3(STRIP_TB, STRIP_TC / K), lds, st, L, v,
-                       starts, work, changed, cols, plan, btiles, ctiles, parity, gate_r2);
-    return hipGetLastError();
-}
-
-hipError_t launch_sweep_strip(const DevLayout &L, const float *v, const StartDesc *starts,
-                              const int2 *work, long long nblocks, bool coop, int *changed,
-                              const StripCol *cols, const StripPlan &plan, int parity,
-                              float gate_r2, hipStream_t st)
-{
-    if (nblocks <= 0) return hipSuccess;
-    if (nblocks > 0x7fffffffLL) return hipErrorInvalidValue;
-    if (coop)
-        return launch_strip_k<STRIP_K, true>(L, v, starts, work, nblocks, changed, cols, plan, parity,
-                                             gate_r2, st);
-    return launch_strip_k<STRIP_K, false>(L, v, starts, work, nblocks, changed, cols, plan, parity,
-                                          gate_r2, st);
-}
-
-// ===========================================================================
-// sparse passes: unit queues drained by a persistent grid
-// ===========================================================================
+// ---------------------------------------------------------------------------
+// a pass: unit queues drained by a persistent grid
+// ---------------------------------------------------------------------------
 //
-// With the distance gate only a shell of units is due in any pass, and most workgroups of a
-// grid-per-unit launch would start, read their neighbours' flags and leave.  Sparse passes
-// therefore run in two steps: plan_pass_kernel (one THREAD per unit) decides which units
+// Activity tracking.  A unit's offsets with plane offset da have to be relaxed in a pass
+// only if a unit they read from (plane a+da, +-1 lane tile, +-1 strip) improved in the
+// previous pass: everything else was already relaxed against unchanged values.  Every
+// unit has a flag word per pass parity (FLAG_* bits: something improved at all / within
+// reach of the strip's low / high border).
+//
+// Distance gate.  Far from the start the first values to arrive (over long edges) are
+// poor and get refined pass after pass; relaxing those units early is wasted work.  A unit
+// is therefore held back until the gate radius (it grows by a fixed number of cells per
+// pass) reaches it.  The plane bits it owes are remembered in pend[] (they accumulate
+// across passes), so holding a unit back never loses an update, and a start with anything
+// pending is not reported as converged.  The gate is for solves that grow from one source
+// unit; a box that arrives with many finite units (e.g. an already converged one) is
+// relaxed ungated.
+//
+// Only a shell of units is due in any pass, and most workgroups of a grid-per-unit launch
+// would start, read their neighbours' flags and leave.  A pass therefore runs in two steps: plan_pass_kernel (one THREAD per unit) decides which units
 // are due and writes them, in work-list order, into one queue per XCD; sweep_units_kernel,
 // a grid of as many workgroups as the chip holds at once, drains the queues (own XCD's
 // first, then the others').  A workgroup relaxes ONE unit at a time, its four waves
@@ -851,7 +525,7 @@ plan_pass_kernel(DevLayout L, const StartDesc *__restrict__ starts, const int2 *
             }
             if (due) planes |= 1u << ia;
         }
-        // distance gate and held-back plane bits: as in sweep_strip_kernel
+        // distance gate and held-back plane bits
         unsigned *__restrict__ pend = reinterpret_cast<unsigned *>(sd.tile_flags + 2 * nunits);
         const int b0 = bt * STRIP_TB, cb0 = cs * STRIP_K;
         const int tb_eff = min(STRIP_TB, L.n[1]);
@@ -891,9 +565,9 @@ sweep_units_kernel(DevLayout L, const float *__restrict__ v, const StartDesc *__
 {
     constexpr int NS = STRIP_NS;
     constexpr int NT = STRIP_TB * NS;
-    constexpr int PWV = K + 2 * STRIP_CF;
-    constexpr int PW = PWV + (((PWV / 4) % 2 == 0) ? 4 : 0);
-    constexpr int F4_PER_ROW = PWV / 4;
+    static_assert(K == STRIP_K, "the slab pitch is derived from STRIP_K");
+    constexpr int PW = STRIP_PW;
+    constexpr int F4_PER_ROW = STRIP_W / 4;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     int *head = reinterpret_cast<int *>(smem);      // [0], [1]: queue index handed to the workgroup
 
@@ -935,13 +609,12 @@ sweep_units_kernel(DevLayout L, const float *__restrict__ v, const StartDesc *__
 
         const StartDesc sd = starts[s];
         float *__restrict__ T = sd.T;
-        if (tid == 0) {     // statistics: cells x offsets relaxed, workgroups, units
+        if (tid == 0) {     // statistics: cells x offsets relaxed, units
             const int wb = min(tb_eff, L.n[1] - b0), wc = max(min(K, L.n[2] - c0), 0);
             int nent = 0;
             for (int ia = 0; ia <= 2 * plan.ra; ia++)
                 if ((my_planes >> ia) & 1u) nent += plan.nent[ia];
             atomicAdd(sd.work, (unsigned long long)(wb * wc) * (unsigned long long)nent);
-            atomicAdd(sd.work + 1, 1ull);
             atomicAdd(sd.work + 2, 1ull);
         }
 
@@ -1040,9 +713,7 @@ sweep_units_kernel(DevLayout L, const float *__restrict__ v, const StartDesc *__
 
 size_t units_lds_bytes(const StripPlan &plan, int nb)
 {
-    constexpr int pwv = STRIP_K + 2 * STRIP_CF;
-    constexpr int pw = pwv + (((pwv / 4) % 2 == 0) ? 4 : 0);
-    size_t floats = (size_t)2 * (std::min(STRIP_TB, nb) + 2 * plan.rb) * pw;
+    size_t floats = (size_t)2 * (std::min(STRIP_TB, nb) + 2 * plan.rb) * STRIP_PW;
     floats = std::max(floats, (size_t)STRIP_NS * STRIP_K * STRIP_TB);       // combine buffer
     return (floats + STRIP_LDS_HEAD) * sizeof(float);
 }
@@ -1052,7 +723,7 @@ hipError_t launch_plan_pass(const DevLayout &L, const StartDesc *starts, const i
                             const StripPlan &plan, int parity, float gate_r2, hipStream_t st)
 {
     if (nwork <= 0) return hipSuccess;
-    const int btiles = (L.n[1] + STRIP_TB - 1) / STRIP_TB;
+    const int btiles = strip_btiles(L);
     // threads: waves of 64 entries, dealt over the 8 sub-lists
     const long long per_list = (nwork + UNITQ_LISTS - 1) / UNITQ_LISTS;
     const long long waves = ((per_list + 63) / 64) * UNITQ_LISTS;
@@ -1070,7 +741,7 @@ hipError_t launch_sweep_units(const DevLayout &L, const float *v, const StartDes
                               int parity, hipStream_t st)
 {
     if (nblocks <= 0) return hipSuccess;
-    const int btiles = (L.n[1] + STRIP_TB - 1) / STRIP_TB;
+    const int btiles = strip_btiles(L);
     auto kern = sweep_units_kernel<STRIP_K>;
     const size_t lds = units_lds_bytes(plan, L.n[1]);
     if (lds > 48 * 1024) {
@@ -1096,7 +767,6 @@ sweep_special_kernel(DevLayout L, const float *__restrict__ v,
                      int *__restrict__ changed, const CellEntry *__restrict__ entries,
                      int nentries, int max_box_cells, int parity)
 {
-    constexpr int k = STRIP_K;
     const int s = active[blockIdx.x / max_box_cells];
     int cell = blockIdx.x % max_box_cells;
     const StartDesc sd = starts[s];
@@ -1129,11 +799,10 @@ sweep_special_kernel(DevLayout L, const float *__restrict__ v,
     if (threadIdx.x == 0 && best < told) {
         T[ci] = best;
         atomicOr(&changed[s], 1);
-        // runs after the STRIP pass of the same parity has written its tile flags
-        const int btiles = (L.n[1] + STRIP_TB - 1) / STRIP_TB;
-        const int cstrips = ((L.n[2] + STRIP_TC - 1) / STRIP_TC) * (STRIP_TC / k);
-        const int nunits = L.n[0] * btiles * cstrips;
-        sd.tile_flags[parity * nunits + (a * btiles + b / STRIP_TB) * cstrips + c / k] = 7;
+        // runs after the unit pass of the same parity has written its flags
+        const int btiles = strip_btiles(L), cstrips = strip_cstrips(L);
+        const int nunits = strip_units(L);
+        sd.tile_flags[parity * nunits + (a * btiles + b / STRIP_TB) * cstrips + c / STRIP_K] = 7;
     }
 }
 
