@@ -200,7 +200,12 @@ static void make_layout_strip(ttsweep_ctx *ctx)
 // Can the STRIP kernel handle this star?  (plane and strip offsets within +-7)
 static bool strip_supported(const ttsweep_ctx *ctx)
 {
-    return !ctx->pull.empty() && ctx->radius <= STRIP_MAX_RA && ctx->radius < STRIP_CF;
+    if (ctx->pull.empty() || ctx->radius > STRIP_MAX_RA || ctx->radius >= STRIP_CF) return false;
+    // the slab loads address the padded volume with 32-bit byte offsets: keep it below 4 GiB
+    // (bound on the padded extents: halo + rounding to whole lane tiles / strips)
+    const double padded = (double)(ctx->nx + 2 * STRIP_MAX_RA + STRIP_TB) * (ctx->ny + 2 * STRIP_MAX_RA + STRIP_TB)
+                        * (ctx->nz + 2 * STRIP_MAX_RA + STRIP_TB);
+    return padded * sizeof(float) < 4294967296.0;
 }
 
 static int upload_strip_plan(ttsweep_ctx *ctx)
@@ -839,6 +844,9 @@ int ttsweep_solve_device(ttsweep_ctx *ctx, int nstart, const ttsweep_start *star
     HIPCHK(hipEventRecord(ctx->ev_solve1, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
 
+#ifdef TTSWEEP_PROFILE
+    prof_dump();
+#endif
     float ms = 0;
     HIPCHK(hipEventElapsedTime(&ms, ctx->ev_solve0, ctx->ev_solve1));
     ctx->stats.solve_ms = ms;

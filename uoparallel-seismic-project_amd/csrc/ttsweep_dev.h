@@ -75,9 +75,6 @@ constexpr int STRIP_NS = 4;                         // waves per workgroup
 constexpr int STRIP_TB = 64;                        // lanes along b
 constexpr int STRIP_CF = 8;                         // halo in front of a strip window (>= max|dc|, multiple of 4)
 constexpr int STRIP_W = STRIP_K + 2 * STRIP_CF;     // neighbour window per (cell strip, column)
-// slab row pitch: STRIP_W valid floats; PW/4 must be odd so that 16 lanes reading float4 at a
-// stride of one row hit 64 distinct banks (MI355X_MICROARCH.md, LDS ds_read_b128)
-constexpr int STRIP_PW = STRIP_W + (((STRIP_W / 4) % 2 == 0) ? 4 : 0);
 constexpr int STRIP_MAX_RA = 7;                     // plane offsets handled: |da| <= 7
 
 // One (da, db) column of the pull star: all offsets that differ only in dc.

@@ -61,4 +61,8 @@ hipError_t launch_sweep_special(const DevLayout &L, const float *v, const StartD
 hipError_t launch_init_tile_flags(const DevLayout &L, const StartDesc &sd, bool from_box,
                                   hipStream_t st);
 
+#ifdef TTSWEEP_PROFILE
+void prof_dump();        // prints and clears the phase counters of sweep_units_kernel
+#endif
+
 } // namespace ttsweep

@@ -273,6 +273,10 @@ hipError_t launch_validate(const DevLayout &L, const float *v, const float *T, l
 // The first words of the dynamic LDS region carry workgroup-wide scalars (no static
 // __shared__ object: it would shift the 16-byte alignment of the dynamic base).
 constexpr int STRIP_LDS_HEAD = 16;      // floats reserved in front of the slabs
+// slab geometry (bytes): up to 64 + 2*7 rows, rounded up to 8, of 128 B for v, then for T
+constexpr int SLAB_MAX_ROWS8 = (STRIP_TB + 2 * STRIP_MAX_RA + 7) / 8 * 8;
+constexpr int SLAB_T_BYTES = SLAB_MAX_ROWS8 * STRIP_W * 4;
+constexpr int SLAB_BYTES = 2 * SLAB_T_BYTES;
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -312,7 +316,9 @@ __device__ __forceinline__ void pin_col(ColRegs &r)
 enum : int { FLAG_ANY = 1, FLAG_LO = 2, FLAG_HI = 4 };
 
 // Relax all offsets dc of one (da, db) column: load the neighbour window from LDS into
-// registers once, then fold every present offset into acc.
+// registers once, then fold every present offset into acc.  row: start of the lane's slab
+// row of v, swb: that row's swizzle in bytes (float4 j of the row is stored at byte
+// (16 j) ^ swb).
 //
 // MASK != 0: the column's dc set is a compile-time constant -> straight-line code.
 // MASK == 0: runtime set (cur.mask), one scalar-branch-selected block per offset.
@@ -323,10 +329,18 @@ enum : int { FLAG_ANY = 1, FLAG_LO = 2, FLAG_HI = 4 };
 // pair: even t -> cells (0,1),(2,3)..; odd t -> cells (1,2),(3,4).., with cells 0 and
 // K-1 done singly.  Measured (tools/microbench/relax_static.hip): straight-line packed
 // blocks sustain ~15 T relaxations/s against ~11 T/s for any scalar form.
+#ifdef TTSWEEP_PROFILE2
+#define g_p2 p2_local
+#define P2_PARAM , long long (&p2_local)[2]
+#define P2_ARG , p2
+#else
+#define P2_PARAM
+#define P2_ARG
+#endif
 template <int K, unsigned MASK>
-__device__ __forceinline__ void relax_column(const ColRegs &cur, const float *pv, const float *pt,
+__device__ __forceinline__ void relax_column(const ColRegs &cur, const char *row, unsigned swb,
                                              const f32x2 (&vce)[K / 2], const f32x2 (&vco)[K / 2 - 1],
-                                             float (&acc)[K])
+                                             float (&acc)[K] P2_PARAM)
 {
     constexpr int W = K + 2 * STRIP_CF;
     constexpr bool STATIC = MASK != 0u;
@@ -342,21 +356,47 @@ __device__ __forceinline__ void relax_column(const ColRegs &cur, const float *pv
                 for (int j = 0; j < W / 4; j++)
                     if (4 * j + 3 >= t && 4 * j <= t + K - 1) chunks |= 1u << j;
     }
-    const f32x4 *pv4 = reinterpret_cast<const f32x4 *>(__builtin_assume_aligned(pv, 16));
-    const f32x4 *pt4 = reinterpret_cast<const f32x4 *>(__builtin_assume_aligned(pt, 16));
+#ifdef TTSWEEP_PROFILE2
+    const long long pc0 = clock64();
+#endif
     f32x2 vN2[W / 2], tN2[W / 2];       // window element w is pair w/2, half w&1
+    static_assert(W / 4 == 8, "the window is 8 float4 wide");
+    f32x4 xw[W / 4], yw[W / 4];
 #pragma unroll
     for (int j = 0; j < W / 4; j++) {
         if (chunks & (1u << j)) {
-            const f32x4 x = pv4[j];
-            const f32x4 y = pt4[j];
-            // keep whole float4s: when a chunk is only partly used the compiler narrows the
-            // load and pairs the pieces into ds_read2_b64 (8 LDS cycles instead of 4)
-            asm volatile("" :: "v"(x), "v"(y));
-            vN2[2 * j] = f32x2{x.x, x.y}; vN2[2 * j + 1] = f32x2{x.z, x.w};
-            tN2[2 * j] = f32x2{y.x, y.y}; tN2[2 * j + 1] = f32x2{y.z, y.w};
+            // slab rows are XOR-swizzled (stage_slab); one v_xad_u32 per float4 pair, the T
+            // row sits at a compile-time distance behind the v row
+            const char *at = row + (swb ^ (unsigned)(16 * j));
+            xw[j] = *reinterpret_cast<const f32x4 *>(at);
+            yw[j] = *reinterpret_cast<const f32x4 *>(at + SLAB_T_BYTES);
         }
     }
+    // (chunks that are not read stand in for a loaded one below: no instructions)
+    constexpr int JF = STATIC ? __builtin_ctz(MASK) / 4 : 0;      // a chunk every column reads
+#pragma unroll
+    for (int j = 0; j < W / 4; j++) {
+        if (!(chunks & (1u << j))) {
+            if (STATIC) { xw[j] = xw[JF]; yw[j] = yw[JF]; }
+            else { xw[j] = f32x4{0.f, 0.f, 0.f, 0.f}; yw[j] = xw[j]; }
+        }
+    }
+    // All loads are issued before the first value is used, and whole float4s are kept: when
+    // a chunk is only partly used the compiler narrows the load and pairs the pieces into
+    // ds_read2_b64 (8 LDS cycles instead of 4).
+    asm volatile("" :: "v"(xw[0]), "v"(xw[1]), "v"(xw[2]), "v"(xw[3]), "v"(xw[4]), "v"(xw[5]),
+                 "v"(xw[6]), "v"(xw[7]), "v"(yw[0]), "v"(yw[1]), "v"(yw[2]), "v"(yw[3]), "v"(yw[4]),
+                 "v"(yw[5]), "v"(yw[6]), "v"(yw[7]));
+#pragma unroll
+    for (int j = 0; j < W / 4; j++) {
+        vN2[2 * j] = f32x2{xw[j].x, xw[j].y}; vN2[2 * j + 1] = f32x2{xw[j].z, xw[j].w};
+        tN2[2 * j] = f32x2{yw[j].x, yw[j].y}; tN2[2 * j + 1] = f32x2{yw[j].z, yw[j].w};
+    }
+#ifdef TTSWEEP_PROFILE2
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    const long long pc1 = clock64();
+    g_p2[0] += pc1 - pc0;
+#endif
 #pragma unroll
     for (int t = 1; t < 2 * STRIP_CF; t++) {
         if (mask & (1u << t)) {
@@ -401,6 +441,10 @@ __device__ __forceinline__ void relax_column(const ColRegs &cur, const float *pv
             }
         }
     }
+#ifdef TTSWEEP_PROFILE2
+    asm volatile("" :: "v"(acc[0]), "v"(acc[K - 1]));
+    g_p2[1] += clock64() - pc1;
+#endif
 }
 
 __global__ void __launch_bounds__(256)
@@ -556,6 +600,76 @@ plan_pass_kernel(DevLayout L, const StartDesc *__restrict__ starts, const int2 *
     }
 }
 
+// Slab of one neighbour plane in LDS: `rows8` rows (rows rounded up to 8) of STRIP_W = 32
+// floats for v and, SLAB_T_BYTES behind them, the same for T.  It is filled by LDS-DMA (global_load_lds_dwordx4: no
+// VGPRs, asynchronous; one wave-instruction writes 1 KiB = 8 whole rows, lane l -> float4
+// l % 8 of row l / 8), so the rows cannot be padded against bank conflicts; instead float4 j
+// of row r is stored at position j ^ ((r >> 1) & 7): 16 consecutive lanes reading the same
+// float4 of 16 consecutive rows then hit all 64 banks (the swizzle is applied to the SOURCE
+// address here and to the read address in relax_column).
+__device__ __forceinline__ int slab_swizzle(int row) { return (row >> 1) & 7; }
+
+//
+// The loads are buffer loads: the (wave-uniform) position of the slab and of the 8-row group
+// goes into the scalar offset, so the per-lane byte offset is the same few values for every
+// plane and group and costs no address arithmetic per instruction.  Offsets are 32-bit: the
+// padded volume must stay below 4 GiB (checked on the host).
+typedef __amdgpu_buffer_rsrc_t buf_rsrc;
+
+__device__ __forceinline__ buf_rsrc make_rsrc(const float *base)
+{
+    // raw buffer, no stride, no range limit; word 3 as for gfx90a/gfx94x/gfx950 raw buffers
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(base), 0, 0x7fffffff, 0x00020000);
+}
+
+__device__ __forceinline__ void stage_slab(buf_rsrc rv, buf_rsrc rt, unsigned src_bytes,
+                                           unsigned s1_bytes, float *slab, int rows, int rows8,
+                                           int wave, int lane)
+{
+    const int ninstr = rows8 / 8;           // wave-instructions per array
+    const int rloc = lane >> 3, p = lane & 7;
+    // row r = 8 kk + rloc has swizzle ((r >> 1) & 7) = (rloc >> 1) ^ (4 (kk & 1))
+    const unsigned lane_row = (unsigned)rloc * s1_bytes;
+    const unsigned voff_even = lane_row + (unsigned)((p ^ (rloc >> 1)) << 4);
+    const unsigned voff_odd = lane_row + (unsigned)((p ^ (rloc >> 1) ^ 4) << 4);
+    for (int k = wave; k < 2 * ninstr; k += STRIP_NS) {
+        const bool is_t = k >= ninstr;
+        const int kk = is_t ? k - ninstr : k;
+        unsigned voff = (kk & 1) ? voff_odd : voff_even;
+        if (kk == ninstr - 1)               // rows past the slab re-read its last row
+            voff -= (unsigned)max(kk * 8 + rloc - (rows - 1), 0) * s1_bytes;
+        const unsigned soff = src_bytes + (unsigned)(kk * 8) * s1_bytes;
+        float *dst = slab + (is_t ? SLAB_T_BYTES / 4 : 0) + kk * (8 * STRIP_W);     // wave-uniform
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(is_t ? rt : rv, (__attribute__((address_space(3))) void *)dst,
+                                                 16, (int)voff, (int)soff, 0, 0);
+    }
+}
+
+// -DTTSWEEP_PROFILE: cycle counts of wave 0 per phase, summed over all units (tuning aid)
+#ifdef TTSWEEP_PROFILE
+__device__ unsigned long long g_prof[8];
+__device__ unsigned long long g_prof2[2];
+#define PROF_T(x) const long long x = clock64()
+void prof_dump()
+{
+    unsigned long long h[8] = {};
+    (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(g_prof), sizeof(h));
+    const double n = (double)std::max<unsigned long long>(h[6], 1);
+    fprintf(stderr, "prof (wave 0, cycles per unit, %llu units): fetch %.0f  prologue %.0f  wait %.0f  stage %.0f  "
+            "compute %.0f  epilogue %.0f  | busy / resident cycles of the workgroups: %.3f\n",
+            h[6], h[0] / n, h[1] / n, h[2] / n, h[3] / n, h[4] / n, h[5] / n,
+            (double)(h[0] + h[1] + h[2] + h[3] + h[4] + h[5]) / (double)std::max<unsigned long long>(h[7], 1));
+    unsigned long long h2[2] = {};
+    (void)hipMemcpyFromSymbol(h2, HIP_SYMBOL(g_prof2), sizeof(h2));
+    fprintf(stderr, "prof2 (inside the columns, cycles per unit): window load + wait %.0f  arithmetic %.0f\n", h2[0] / n, h2[1] / n);
+    unsigned long long z[8] = {};
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_prof), z, sizeof(z));
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_prof2), z, sizeof(h2));
+}
+#else
+#define PROF_T(x)
+#endif
+
 template <int K>
 __global__ void __launch_bounds__(STRIP_TB *STRIP_NS, 3)
 sweep_units_kernel(DevLayout L, const float *__restrict__ v, const StartDesc *__restrict__ starts,
@@ -564,10 +678,7 @@ sweep_units_kernel(DevLayout L, const float *__restrict__ v, const StartDesc *__
                    int btiles, int cstrips, int parity)
 {
     constexpr int NS = STRIP_NS;
-    constexpr int NT = STRIP_TB * NS;
-    static_assert(K == STRIP_K, "the slab pitch is derived from STRIP_K");
-    constexpr int PW = STRIP_PW;
-    constexpr int F4_PER_ROW = STRIP_W / 4;
+    static_assert(K == STRIP_K && STRIP_W == 32, "slab rows are 8 float4 wide");
     extern __shared__ __attribute__((aligned(16))) float smem[];
     int *head = reinterpret_cast<int *>(smem);      // [0], [1]: queue index handed to the workgroup
 
@@ -578,17 +689,24 @@ sweep_units_kernel(DevLayout L, const float *__restrict__ v, const StartDesc *__
     const int tb_eff = min(STRIP_TB, L.n[1]);
     const int rows = tb_eff + 2 * rb;
     const int lane_r = min(lane, tb_eff - 1);
-    const int nf4 = rows * F4_PER_ROW;
+    const int rows8 = (rows + 7) & ~7;
+    constexpr int slab_floats = SLAB_BYTES / 4;     // v rows, then T rows
     const int nunits = L.n[0] * btiles * cstrips;
-    float *sv = smem + STRIP_LDS_HEAD;
-    float *sT = sv + rows * PW;
+    float *slabs = smem + STRIP_LDS_HEAD;           // two slabs (double buffer)
     float *comb = smem + STRIP_LDS_HEAD;            // [wave][cell][lane], aliases the slabs
+    unsigned plane_mask = 0;                        // plane offsets that have columns at all
+    for (int ia = 0; ia <= 2 * plan.ra; ia++)
+        if (plan.first[ia] != plan.first[ia + 1]) plane_mask |= 1u << ia;
 
+    const buf_rsrc rv = make_rsrc(v);
+
+    PROF_T(t_k0);
     const int home = blockIdx.x % UNITQ_LISTS;
     int probe = 0, it = 0;
     while (probe < UNITQ_LISTS) {
         // ---- take the next unit of queue q (every wave leaves through the same exit:
         // all queues exhausted)
+        PROF_T(t_top);
         const int q = (home + probe) % UNITQ_LISTS;
         const int n = ctrl[q];
         if (tid == 0) head[it & 1] = ctrl[UNITQ_LISTS + q] < n ? atomicAdd(&ctrl[UNITQ_LISTS + q], 1) : n;
@@ -596,6 +714,13 @@ sweep_units_kernel(DevLayout L, const float *__restrict__ v, const StartDesc *__
         const int j = __builtin_amdgcn_readfirstlane(head[it & 1]);
         it++;
         if (j >= n) { probe++; continue; }
+        PROF_T(t_fetch);
+#ifdef TTSWEEP_PROFILE
+        long long p_wait = 0, p_stage = 0, p_comp = 0;
+#endif
+#ifdef TTSWEEP_PROFILE2
+        long long p2[2] = {0, 0};
+#endif
         const int4 item = lists[(size_t)q * list_cap + j];
         const int s = __builtin_amdgcn_readfirstlane(item.x);
         const int my_unit = __builtin_amdgcn_readfirstlane(item.y);
@@ -618,6 +743,19 @@ sweep_units_kernel(DevLayout L, const float *__restrict__ v, const StartDesc *__
             atomicAdd(sd.work + 2, 1ull);
         }
 
+        // ---- planes to relax, in order; the first one starts to load right away.  Slab of
+        // plane a+da: rows b0-rb .. b0+63+rb, columns c0-CF .. c0+K+CF-1.
+        unsigned todo = my_planes & plane_mask;
+        const unsigned src0 = (unsigned)(((long long)(a - plan.ra + L.lo[0]) * L.s0
+                                          + (long long)(b0 - rb + L.lo[1]) * L.s1
+                                          + (c0 - STRIP_CF + L.lo[2])) * 4);          // bytes
+        const unsigned s0_bytes = (unsigned)(L.s0 * 4), s1_bytes = (unsigned)(L.s1 * 4);
+        const buf_rsrc rt = make_rsrc(T);
+        int buf = 0;
+        if (todo)
+            stage_slab(rv, rt, src0 + (unsigned)__builtin_ctz(todo) * s0_bytes, s1_bytes, slabs, rows,
+                       rows8, wave, lane);
+
         // own cells: (a, b0 + lane, c0 + q)
         const long long own = (long long)(a + L.lo[0]) * L.s0 + (long long)(b0 + lane_r + L.lo[1]) * L.s1
                             + (c0 + L.lo[2]);
@@ -634,43 +772,52 @@ sweep_units_kernel(DevLayout L, const float *__restrict__ v, const StartDesc *__
 #pragma unroll
         for (int p = 0; p < K / 2 - 1; p++) vco[p] = f32x2{vce[p].y, vce[p + 1].x};
 
-        for (int ia = 0; ia <= 2 * plan.ra; ia++) {
-            if (plan.first[ia] == plan.first[ia + 1] || !((my_planes >> ia) & 1u)) continue;
-            const int da = ia - plan.ra;
-            // ---- stage plane a+da: rows b0-rb .. b0+63+rb, columns c0-CF .. c0+K+CF-1
-            const long long src = (long long)(a + da + L.lo[0]) * L.s0
-                                + (long long)(b0 - rb + L.lo[1]) * L.s1 + (c0 - STRIP_CF + L.lo[2]);
-            __syncthreads();            // everybody is done reading the previous slab
-            for (int f = tid; f < nf4; f += NT) {
-                const int r = f / F4_PER_ROW;
-                const int c4 = f - r * F4_PER_ROW;
-                const long long g = src + (long long)r * L.s1 + 4 * c4;
-                const float4 xv = *reinterpret_cast<const float4 *>(v + g);
-                const float4 xt = *reinterpret_cast<const float4 *>(T + g);
-                *reinterpret_cast<float4 *>(sv + r * PW + 4 * c4) = xv;
-                *reinterpret_cast<float4 *>(sT + r * PW + 4 * c4) = xt;
-            }
+        PROF_T(t_pro);
+        while (todo) {
+            const int ia = __builtin_ctz(todo);
+            todo &= todo - 1;
+            PROF_T(t0);
+            // this wave's part of slab `ia` has landed ...
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            // ... and so has everybody else's; the other slab is no longer read
             __syncthreads();
+            PROF_T(t1);
+            // the next plane loads into the other slab while this one is relaxed
+            if (todo)
+                stage_slab(rv, rt, src0 + (unsigned)__builtin_ctz(todo) * s0_bytes, s1_bytes,
+                           slabs + (buf ^ 1) * slab_floats, rows, rows8, wave, lane);
+            PROF_T(t2);
+#ifdef TTSWEEP_PROFILE
+            p_wait += t1 - t0; p_stage += t2 - t1;
+#endif
 
             // ---- this wave's share of the plane offset's columns
+            const float *sv = slabs + buf * slab_floats;
             const int cbeg = plan.first[ia] + plan.wsplit[ia][wave];
             const int cend = plan.first[ia] + plan.wsplit[ia][wave + 1];
-            if (cbeg >= cend) continue;
-            ColRegs cur = load_col(cols, cbeg);
-            for (int ci = cbeg; ci < cend; ci++) {
-                pin_col(cur);
-                const ColRegs nxt = load_col(cols, min(ci + 1, cend - 1));
-                const float *pv = sv + (lane_r + rb + cur.rowoff) * PW;
-                const float *pt = pv + rows * PW;
-                switch (cur.mask) {
-#define STRIP_MASK_CASE(m) case m: relax_column<K, m>(cur, pv, pt, vce, vco, acc); break;
+            if (cbeg < cend) {
+                ColRegs cur = load_col(cols, cbeg);
+                for (int ci = cbeg; ci < cend; ci++) {
+                    pin_col(cur);
+                    const ColRegs nxt = load_col(cols, min(ci + 1, cend - 1));
+                    const int row = lane_r + rb + cur.rowoff;
+                    const char *prow = reinterpret_cast<const char *>(sv) + row * (STRIP_W * 4);
+                    const unsigned swb = (unsigned)slab_swizzle(row) << 4;
+                    switch (cur.mask) {
+#define STRIP_MASK_CASE(m) case m: relax_column<K, m>(cur, prow, swb, vce, vco, acc P2_ARG); break;
 #include "strip_masks.inc"
 #undef STRIP_MASK_CASE
-                default: relax_column<K, 0u>(cur, pv, pt, vce, vco, acc); break;
+                    default: relax_column<K, 0u>(cur, prow, swb, vce, vco, acc P2_ARG); break;
+                    }
+                    cur = nxt;
                 }
-                cur = nxt;
             }
+            buf ^= 1;
+#ifdef TTSWEEP_PROFILE
+            p_comp += clock64() - t2;
+#endif
         }
+        PROF_T(t_loop);
 
         // ---- min-combine the waves' partial results; wave w finishes cells 4w .. 4w+3
         __syncthreads();                // the last slab is no longer read
@@ -708,12 +855,32 @@ sweep_units_kernel(DevLayout L, const float *__restrict__ v, const StartDesc *__
             atomicOr(sd.tile_flags + parity * nunits + my_unit, improved);
             atomicOr(&changed[s], 1);
         }
+#ifdef TTSWEEP_PROFILE
+        if (tid == 0) {
+            const long long t_end = clock64();
+            atomicAdd(&g_prof[0], (unsigned long long)(t_fetch - t_top));
+            atomicAdd(&g_prof[1], (unsigned long long)(t_pro - t_fetch));
+            atomicAdd(&g_prof[2], (unsigned long long)p_wait);
+            atomicAdd(&g_prof[3], (unsigned long long)p_stage);
+            atomicAdd(&g_prof[4], (unsigned long long)p_comp);
+            atomicAdd(&g_prof[5], (unsigned long long)(t_end - t_loop));
+            atomicAdd(&g_prof[6], 1ull);
+#ifdef TTSWEEP_PROFILE2
+            atomicAdd(&g_prof2[0], (unsigned long long)p2[0]);
+            atomicAdd(&g_prof2[1], (unsigned long long)p2[1]);
+#endif
+        }
+#endif
     }
+#ifdef TTSWEEP_PROFILE
+    if (tid == 0) atomicAdd(&g_prof[7], (unsigned long long)(clock64() - t_k0));
+#endif
 }
 
 size_t units_lds_bytes(const StripPlan &plan, int nb)
 {
-    size_t floats = (size_t)2 * (std::min(STRIP_TB, nb) + 2 * plan.rb) * STRIP_PW;
+    (void)plan; (void)nb;
+    size_t floats = (size_t)2 * SLAB_BYTES / 4;                             // two slabs of v and T rows
     floats = std::max(floats, (size_t)STRIP_NS * STRIP_K * STRIP_TB);       // combine buffer
     return (floats + STRIP_LDS_HEAD) * sizeof(float);
 }
