@@ -450,7 +450,7 @@ static int build_worklist(ttsweep_ctx *ctx, int nactive)
         HIPCHK(hipMalloc((void **)&ctx->d_unitq, longest * UNITQ_LISTS * sizeof(int4)));
         ctx->unitq_cap = longest;
     }
-    if (!ctx->d_unitq_ctrl) HIPCHK(hipMalloc((void **)&ctx->d_unitq_ctrl, UNITQ_CTRL_WORDS * sizeof(int)));
+    if (!ctx->d_unitq_ctrl) HIPCHK(hipMalloc((void **)&ctx->d_unitq_ctrl, (UNITQ_CTRL_WORDS + 1) * sizeof(int)));
     if (ctx->unitq_blocks == 0) {
         hipDeviceProp_t prop;
         HIPCHK(hipGetDeviceProperties(&prop, ctx->device));
@@ -493,21 +493,29 @@ static float gate_r2(const ttsweep_ctx *ctx)
 }
 
 // One full-grid pass for the active starts.
-static int launch_pass(ttsweep_ctx *ctx, int nactive, int *d_changed)
+// STRIP: the pass's "changed" words arrive in h_changed_slot without a copy command, and
+// d_changed_next is cleared for the pass after this one (UnitPassTail).
+static int launch_pass(ttsweep_ctx *ctx, int nactive, int nstart, int *d_changed, int *h_changed_slot,
+                       int *d_changed_next)
 {
     hipEvent_t e0, e1;
     if (ctx->timing && timed_event(ctx, &e0)) return -1;
     if (ctx->kernel == TTSWEEP_KERNEL_STRIP) {
-        HIPCHK(hipMemsetAsync(ctx->d_unitq_ctrl, 0, UNITQ_CTRL_WORDS * sizeof(int), ctx->stream));
         HIPCHK(launch_plan_pass(ctx->L, ctx->d_starts, ctx->d_worklist, ctx->worklist_len, d_changed,
                                 ctx->d_unitq, (int)ctx->unitq_cap, ctx->d_unitq_ctrl, ctx->plan,
                                 ctx->pass_index & 1, gate_r2(ctx), ctx->stream));
+        UnitPassTail tail;
+        tail.active = ctx->d_active;
+        tail.nactive = nactive;
+        tail.entries = ctx->d_cell_entries;
+        tail.nentries = ctx->n_cell_entries;
+        tail.max_box_cells = (int)ctx->max_box_cells;
+        tail.nstart = nstart;
+        tail.changed_host = h_changed_slot;
+        tail.changed_next = d_changed_next;
         HIPCHK(launch_sweep_units(ctx->L, ctx->d_v, ctx->d_starts, ctx->d_unitq, (int)ctx->unitq_cap,
                                   ctx->d_unitq_ctrl, ctx->unitq_blocks, d_changed, ctx->d_strip_cols,
-                                  ctx->plan, ctx->pass_index & 1, ctx->stream));
-        HIPCHK(launch_sweep_special(ctx->L, ctx->d_v, ctx->d_starts, ctx->d_active, nactive,
-                                    d_changed, ctx->d_cell_entries, ctx->n_cell_entries,
-                                    ctx->max_box_cells, ctx->pass_index & 1, ctx->stream));
+                                  ctx->plan, ctx->pass_index & 1, tail, ctx->stream));
     } else {
         HIPCHK(launch_sweep_cell(ctx->L, ctx->d_v, ctx->d_starts, ctx->d_active, nactive,
                                  d_changed, ctx->d_cell_entries, ctx->n_cell_entries,
@@ -761,7 +769,12 @@ int ttsweep_solve_device(ttsweep_ctx *ctx, int nstart, const ttsweep_start *star
                           hipMemcpyHostToDevice, ctx->stream));
     HIPCHK(hipMemsetAsync(ctx->d_work, 0, 3 * nstart * sizeof(unsigned long long), ctx->stream));
     ctx->pass_index = 0;
-    if (ctx->kernel == TTSWEEP_KERNEL_STRIP && build_worklist(ctx, nstart)) return -1;
+    if (ctx->kernel == TTSWEEP_KERNEL_STRIP) {
+        if (build_worklist(ctx, nstart)) return -1;
+        // the passes keep these cleared themselves from here on
+        HIPCHK(hipMemsetAsync(ctx->d_changed, 0, (size_t)PASS_SLOTS * nstart * sizeof(int), ctx->stream));
+        HIPCHK(hipMemsetAsync(ctx->d_unitq_ctrl, 0, (UNITQ_CTRL_WORDS + 1) * sizeof(int), ctx->stream));
+    }
 
     // driver loop: serial_new/...:151-170 without the break (:168-169).  Passes are
     // enqueued ONE AHEAD of the convergence test: pass k+1 is already running while the
@@ -779,10 +792,15 @@ int ttsweep_solve_device(ttsweep_ctx *ctx, int nstart, const ttsweep_start *star
         if (nactive > 0 && launched - processed < 2) {          // enqueue the next pass
             const int slot = launched % PASS_SLOTS;
             int *dch = ctx->d_changed + (size_t)slot * nstart;
-            HIPCHK(hipMemsetAsync(dch, 0, nstart * sizeof(int), ctx->stream));
-            if (launch_pass(ctx, nactive, dch)) return -1;
-            HIPCHK(hipMemcpyAsync(ctx->h_changed + (size_t)slot * nstart, dch, nstart * sizeof(int),
-                                  hipMemcpyDeviceToHost, ctx->stream));
+            int *hch_slot = ctx->h_changed + (size_t)slot * nstart;
+            const bool strip = ctx->kernel == TTSWEEP_KERNEL_STRIP;
+            if (!strip) HIPCHK(hipMemsetAsync(dch, 0, nstart * sizeof(int), ctx->stream));
+            if (launch_pass(ctx, nactive, nstart, dch, hch_slot,
+                            ctx->d_changed + (size_t)((launched + 1) % PASS_SLOTS) * nstart))
+                return -1;
+            if (!strip)
+                HIPCHK(hipMemcpyAsync(hch_slot, dch, nstart * sizeof(int), hipMemcpyDeviceToHost,
+                                      ctx->stream));
             HIPCHK(hipEventRecord(ctx->ev_flags[slot], ctx->stream));
             snapshot[slot].assign(ctx->h_active, ctx->h_active + nactive);
             launched++;

@@ -104,6 +104,19 @@ __host__ __device__ inline int strip_units(const DevLayout &L) { return L.n[0] *
 // Unit queues of one pass (sweep_units_kernel): 8 lists, one per XCD, filled by
 // plan_pass_kernel.  ctrl[0..7] = entries in list x, ctrl[8..15] = next entry to hand out.
 constexpr int UNITQ_LISTS = 8;
-constexpr int UNITQ_CTRL_WORDS = 2 * UNITQ_LISTS;
+constexpr int UNITQ_CTRL_WORDS = 2 * UNITQ_LISTS;       // followed by one "workgroups done" word
+
+// What sweep_units_kernel does besides draining the queues: the dead-edge cells of the
+// active starts at its beginning, the hand-over of the pass at its end.
+struct UnitPassTail {
+    const int *active;          // indices of the active starts
+    int nactive;
+    const CellEntry *entries;   // whole pull star, for the dead-edge cells
+    int nentries;
+    int max_box_cells;          // cells of the largest dead-edge box
+    int nstart;                 // "changed" words per pass
+    int *changed_host;          // pinned host copy of this pass's words (written at the end)
+    int *changed_next;          // the next pass's device words (cleared at the end)
+};
 
 } // namespace ttsweep

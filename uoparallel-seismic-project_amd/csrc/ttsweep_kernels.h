@@ -33,10 +33,13 @@ hipError_t launch_validate(const DevLayout &L, const float *v, const float *T, l
 
 // ---- sweep, variant STRIP --------------------------------------------------
 // Same contract as launch_sweep_cell, but cells inside a start's dead-edge box
-// (StartDesc::box_*) are left untouched; launch_sweep_special relaxes exactly
-// those cells with the full liveness rule.
+// (StartDesc::box_*) are left untouched by the unit relaxation; the same kernel relaxes
+// exactly those cells with the full liveness rule (one wave per cell).
 //
-// A pass = launch_plan_pass + launch_sweep_units (+ launch_sweep_special).  `parity` =
+// A pass = launch_plan_pass + launch_sweep_units, nothing else: the last workgroup of
+// sweep_units hands the "changed" words to the host and clears the counters (ctrl: the
+// UNITQ_CTRL_WORDS queue words + one "workgroups done" word, all zero before the first
+// pass) and the next pass's "changed" words.  `parity` =
 // pass index & 1 selects which half of StartDesc::tile_flags the pass writes.
 // plan_pass: one thread per entry of the static work list `work`: work[i] = (start index,
 // unit id = (a*btiles + bt)*cstrips + cs) or unit id < 0 for padding; entry i belongs to
@@ -51,11 +54,7 @@ hipError_t launch_plan_pass(const DevLayout &L, const StartDesc *starts, const i
 hipError_t launch_sweep_units(const DevLayout &L, const float *v, const StartDesc *starts,
                               const int4 *lists, int list_cap, int *ctrl, int nblocks,
                               int *changed, const StripCol *cols, const StripPlan &plan,
-                              int parity, hipStream_t st);
-hipError_t launch_sweep_special(const DevLayout &L, const float *v, const StartDesc *starts,
-                                const int *active, int nactive, int *changed,
-                                const CellEntry *entries, int nentries, int max_box_cells,
-                                int parity, hipStream_t st);
+                              int parity, const UnitPassTail &tail, hipStream_t st);
 // First activity flags of a start: from_box = false: only the start's unit is a source;
 // from_box = true: every unit that holds a finite travel time is one.
 hipError_t launch_init_tile_flags(const DevLayout &L, const StartDesc &sd, bool from_box,

@@ -268,11 +268,12 @@ hipError_t launch_validate(const DevLayout &L, const float *v, const float *T, l
 //
 // The relaxation is branch-free: there are no bounds tests (halo cells hold
 // +INF / 0) and no liveness tests.  The few cells that own a dead edge (inside
-// StartDesc::box) are computed but not stored; sweep_special_kernel owns them.
+// StartDesc::box) are computed but not stored; relax_special_cell owns them.
 
 // The first words of the dynamic LDS region carry workgroup-wide scalars (no static
 // __shared__ object: it would shift the 16-byte alignment of the dynamic base).
-constexpr int STRIP_LDS_HEAD = 16;      // floats reserved in front of the slabs
+constexpr int STRIP_LDS_HEAD = 16 + 64;     // words reserved in front of the slabs: 16 scalars, then
+                                            // the waves' column ranges per plane offset (sweep_units_kernel)
 // slab geometry (bytes): up to 64 + 2*7 rows, rounded up to 8, of 128 B for v, then for T
 constexpr int SLAB_MAX_ROWS8 = (STRIP_TB + 2 * STRIP_MAX_RA + 7) / 8 * 8;
 constexpr int SLAB_T_BYTES = SLAB_MAX_ROWS8 * STRIP_W * 4;
@@ -331,7 +332,7 @@ enum : int { FLAG_ANY = 1, FLAG_LO = 2, FLAG_HI = 4 };
 // blocks sustain ~15 T relaxations/s against ~11 T/s for any scalar form.
 #ifdef TTSWEEP_PROFILE2
 #define g_p2 p2_local
-#define P2_PARAM , long long (&p2_local)[2]
+#define P2_PARAM , long long (&p2_local)[4]
 #define P2_ARG , p2
 #else
 #define P2_PARAM
@@ -600,6 +601,53 @@ plan_pass_kernel(DevLayout L, const StartDesc *__restrict__ starts, const int2 *
     }
 }
 
+// ---------------------------------------------------------------------------
+// dead-edge cells: the cells inside StartDesc::box own an edge the reference never
+// relaxes ({start, start - last offset}); one wave relaxes one such cell against the whole
+// star with the full liveness rule (PULL_FWD entries are dead iff the cell is the start,
+// PULL_REV entries iff the neighbour is).  Called by every wave of sweep_units_kernel
+// before it turns to the unit queues.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ void relax_special_cell(const DevLayout &L, const float *__restrict__ v,
+                                                   const StartDesc &sd, int s, int cell,
+                                                   int *__restrict__ changed,
+                                                   const CellEntry *__restrict__ entries,
+                                                   int nentries, int parity, int lane)
+{
+    const int ea = sd.box_hi[0] - sd.box_lo[0] + 1;
+    const int eb = sd.box_hi[1] - sd.box_lo[1] + 1;
+    const int ec = sd.box_hi[2] - sd.box_lo[2] + 1;
+    if (ea <= 0 || eb <= 0 || ec <= 0 || cell >= ea * eb * ec) return;
+    const int c = sd.box_lo[2] + cell % ec; cell /= ec;
+    const int b = sd.box_lo[1] + cell % eb; cell /= eb;
+    const int a = sd.box_lo[0] + cell;
+
+    float *__restrict__ T = sd.T;
+    const long long ci = dev_index(L, a, b, c);
+    const bool c_is_start = (ci == sd.sidx);
+    const float vc = v[ci];
+    const float told = T[ci];
+    float best = told;
+    for (int e = lane; e < nentries; e += 64) {
+        const CellEntry en = entries[e];
+        const long long oi = ci + en.delta;
+        const bool live = ((en.flags & PULL_FWD) && !c_is_start)
+                       || ((en.flags & PULL_REV) && oi != sd.sidx);
+        const float sum = vc + v[oi];
+        const float delay = en.h * sum;
+        const float cand = delay + T[oi];
+        if (live && cand < best) best = cand;
+    }
+#pragma unroll
+    for (int w = 32; w >= 1; w >>= 1) best = fminf(best, __shfl_xor(best, w));
+    if (lane == 0 && best < told) {
+        T[ci] = best;
+        atomicOr(&changed[s], 1);
+        const int btiles = strip_btiles(L), cstrips = strip_cstrips(L);
+        atomicOr(sd.tile_flags + parity * strip_units(L) + (a * btiles + b / STRIP_TB) * cstrips + c / STRIP_K, 7);
+    }
+}
+
 // Slab of one neighbour plane in LDS: `rows8` rows (rows rounded up to 8) of STRIP_W = 32
 // floats for v and, SLAB_T_BYTES behind them, the same for T.  It is filled by LDS-DMA (global_load_lds_dwordx4: no
 // VGPRs, asynchronous; one wave-instruction writes 1 KiB = 8 whole rows, lane l -> float4
@@ -648,7 +696,7 @@ __device__ __forceinline__ void stage_slab(buf_rsrc rv, buf_rsrc rt, unsigned sr
 // -DTTSWEEP_PROFILE: cycle counts of wave 0 per phase, summed over all units (tuning aid)
 #ifdef TTSWEEP_PROFILE
 __device__ unsigned long long g_prof[8];
-__device__ unsigned long long g_prof2[2];
+__device__ unsigned long long g_prof2[4];
 #define PROF_T(x) const long long x = clock64()
 void prof_dump()
 {
@@ -659,9 +707,10 @@ void prof_dump()
             "compute %.0f  epilogue %.0f  | busy / resident cycles of the workgroups: %.3f\n",
             h[6], h[0] / n, h[1] / n, h[2] / n, h[3] / n, h[4] / n, h[5] / n,
             (double)(h[0] + h[1] + h[2] + h[3] + h[4] + h[5]) / (double)std::max<unsigned long long>(h[7], 1));
-    unsigned long long h2[2] = {};
+    unsigned long long h2[4] = {};
     (void)hipMemcpyFromSymbol(h2, HIP_SYMBOL(g_prof2), sizeof(h2));
-    fprintf(stderr, "prof2 (inside the columns, cycles per unit): window load + wait %.0f  arithmetic %.0f\n", h2[0] / n, h2[1] / n);
+    fprintf(stderr, "prof2 (wave 0, cycles per unit): %.1f columns: whole column loop %.0f, of it window load + wait %.0f, "
+            "arithmetic %.0f\n", h2[3] / n, h2[2] / n, h2[0] / n, h2[1] / n);
     unsigned long long z[8] = {};
     (void)hipMemcpyToSymbol(HIP_SYMBOL(g_prof), z, sizeof(z));
     (void)hipMemcpyToSymbol(HIP_SYMBOL(g_prof2), z, sizeof(h2));
@@ -675,7 +724,7 @@ __global__ void __launch_bounds__(STRIP_TB *STRIP_NS, 3)
 sweep_units_kernel(DevLayout L, const float *__restrict__ v, const StartDesc *__restrict__ starts,
                    const int4 *__restrict__ lists, int list_cap, int *__restrict__ ctrl,
                    int *__restrict__ changed, const StripCol *__restrict__ cols, StripPlan plan,
-                   int btiles, int cstrips, int parity)
+                   int btiles, int cstrips, int parity, UnitPassTail tail)
 {
     constexpr int NS = STRIP_NS;
     static_assert(K == STRIP_K && STRIP_W == 32, "slab rows are 8 float4 wide");
@@ -694,11 +743,31 @@ sweep_units_kernel(DevLayout L, const float *__restrict__ v, const StartDesc *__
     const int nunits = L.n[0] * btiles * cstrips;
     float *slabs = smem + STRIP_LDS_HEAD;           // two slabs (double buffer)
     float *comb = smem + STRIP_LDS_HEAD;            // [wave][cell][lane], aliases the slabs
+    const int ncols = plan.first[2 * plan.ra + 1];
     unsigned plane_mask = 0;                        // plane offsets that have columns at all
     for (int ia = 0; ia <= 2 * plan.ra; ia++)
         if (plan.first[ia] != plan.first[ia + 1]) plane_mask |= 1u << ia;
+    // column range [lo, hi) of wave w for plane offset ia, packed lo | hi << 16, in LDS: read
+    // once per plane with LDS latency instead of a chain of scalar memory loads
+    int *col_range = reinterpret_cast<int *>(smem) + 16;
+    if (tid < NS * 16) {
+        const int w = tid >> 4, ia = tid & 15;
+        int packed = 0;
+        if (ia <= 2 * plan.ra)
+            packed = (plan.first[ia] + plan.wsplit[ia][w]) | ((plan.first[ia] + plan.wsplit[ia][w + 1]) << 16);
+        col_range[tid] = packed;
+    }
+    __syncthreads();
 
     const buf_rsrc rv = make_rsrc(v);
+
+    // ---- the dead-edge cells of the active starts, one wave per cell
+    for (int w = blockIdx.x * NS + wave; w < tail.nactive * tail.max_box_cells; w += gridDim.x * NS) {
+        const int s = tail.active[w / tail.max_box_cells];
+        const StartDesc sd = starts[s];
+        relax_special_cell(L, v, sd, s, w % tail.max_box_cells, changed, tail.entries, tail.nentries,
+                           parity, lane);
+    }
 
     PROF_T(t_k0);
     const int home = blockIdx.x % UNITQ_LISTS;
@@ -719,7 +788,7 @@ sweep_units_kernel(DevLayout L, const float *__restrict__ v, const StartDesc *__
         long long p_wait = 0, p_stage = 0, p_comp = 0;
 #endif
 #ifdef TTSWEEP_PROFILE2
-        long long p2[2] = {0, 0};
+        long long p2[4] = {0, 0, 0, 0};
 #endif
         const int4 item = lists[(size_t)q * list_cap + j];
         const int s = __builtin_amdgcn_readfirstlane(item.x);
@@ -755,6 +824,10 @@ sweep_units_kernel(DevLayout L, const float *__restrict__ v, const StartDesc *__
         if (todo)
             stage_slab(rv, rt, src0 + (unsigned)__builtin_ctz(todo) * s0_bytes, s1_bytes, slabs, rows,
                        rows8, wave, lane);
+        // descriptor of the first column this wave will relax (later ones are requested one
+        // column ahead, across plane boundaries)
+        ColRegs cur = load_col(cols, min(__builtin_amdgcn_readfirstlane(col_range[wave * 16 + (todo ? __builtin_ctz(todo) : 0)]) & 0xffff,
+                                         ncols - 1));
 
         // own cells: (a, b0 + lane, c0 + q)
         const long long own = (long long)(a + L.lo[0]) * L.s0 + (long long)(b0 + lane_r + L.lo[1]) * L.s1
@@ -777,6 +850,13 @@ sweep_units_kernel(DevLayout L, const float *__restrict__ v, const StartDesc *__
             const int ia = __builtin_ctz(todo);
             todo &= todo - 1;
             PROF_T(t0);
+            // this wave's share of the plane offset's columns, and where it continues in the
+            // next plane
+            const int range = __builtin_amdgcn_readfirstlane(col_range[wave * 16 + ia]);
+            const int cbeg = range & 0xffff, cend = range >> 16;
+            const int next_first = todo
+                ? min(__builtin_amdgcn_readfirstlane(col_range[wave * 16 + __builtin_ctz(todo)]) & 0xffff, ncols - 1)
+                : 0;
             // this wave's part of slab `ia` has landed ...
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             // ... and so has everybody else's; the other slab is no longer read
@@ -791,27 +871,28 @@ sweep_units_kernel(DevLayout L, const float *__restrict__ v, const StartDesc *__
             p_wait += t1 - t0; p_stage += t2 - t1;
 #endif
 
-            // ---- this wave's share of the plane offset's columns
             const float *sv = slabs + buf * slab_floats;
-            const int cbeg = plan.first[ia] + plan.wsplit[ia][wave];
-            const int cend = plan.first[ia] + plan.wsplit[ia][wave + 1];
-            if (cbeg < cend) {
-                ColRegs cur = load_col(cols, cbeg);
-                for (int ci = cbeg; ci < cend; ci++) {
-                    pin_col(cur);
-                    const ColRegs nxt = load_col(cols, min(ci + 1, cend - 1));
-                    const int row = lane_r + rb + cur.rowoff;
-                    const char *prow = reinterpret_cast<const char *>(sv) + row * (STRIP_W * 4);
-                    const unsigned swb = (unsigned)slab_swizzle(row) << 4;
-                    switch (cur.mask) {
+            for (int ci = cbeg; ci < cend; ci++) {
+#ifdef TTSWEEP_PROFILE2
+                const long long tc0 = clock64();
+#endif
+                pin_col(cur);
+                const ColRegs nxt = load_col(cols, ci + 1 < cend ? ci + 1 : next_first);
+                const int row = lane_r + rb + cur.rowoff;
+                const char *prow = reinterpret_cast<const char *>(sv) + row * (STRIP_W * 4);
+                const unsigned swb = (unsigned)slab_swizzle(row) << 4;
+                switch (cur.mask) {
 #define STRIP_MASK_CASE(m) case m: relax_column<K, m>(cur, prow, swb, vce, vco, acc P2_ARG); break;
 #include "strip_masks.inc"
 #undef STRIP_MASK_CASE
-                    default: relax_column<K, 0u>(cur, prow, swb, vce, vco, acc P2_ARG); break;
-                    }
-                    cur = nxt;
+                default: relax_column<K, 0u>(cur, prow, swb, vce, vco, acc P2_ARG); break;
                 }
+#ifdef TTSWEEP_PROFILE2
+                p2[2] += clock64() - tc0; p2[3] += 1;
+#endif
+                cur = nxt;
             }
+            if (cbeg >= cend) cur = load_col(cols, next_first);     // (no column of this plane was ours)
             buf ^= 1;
 #ifdef TTSWEEP_PROFILE
             p_comp += clock64() - t2;
@@ -868,6 +949,8 @@ sweep_units_kernel(DevLayout L, const float *__restrict__ v, const StartDesc *__
 #ifdef TTSWEEP_PROFILE2
             atomicAdd(&g_prof2[0], (unsigned long long)p2[0]);
             atomicAdd(&g_prof2[1], (unsigned long long)p2[1]);
+            atomicAdd(&g_prof2[2], (unsigned long long)p2[2]);
+            atomicAdd(&g_prof2[3], (unsigned long long)p2[3]);
 #endif
         }
 #endif
@@ -875,6 +958,24 @@ sweep_units_kernel(DevLayout L, const float *__restrict__ v, const StartDesc *__
 #ifdef TTSWEEP_PROFILE
     if (tid == 0) atomicAdd(&g_prof[7], (unsigned long long)(clock64() - t_k0));
 #endif
+
+    // ---- the last workgroup to leave closes the pass: it hands the "changed" words to the
+    // host (pinned memory) and clears the queue counters and the next pass's words, so a pass
+    // needs no memset / copy commands around its two kernels
+    __syncthreads();
+    if (tid == 0) {
+        __threadfence();
+        int *done = ctrl + UNITQ_CTRL_WORDS;
+        if (atomicAdd(done, 1) == (int)gridDim.x - 1) {
+            for (int s = 0; s < tail.nstart; s++) {
+                tail.changed_host[s] = atomicOr(&changed[s], 0);
+                tail.changed_next[s] = 0;
+            }
+            for (int k = 0; k < UNITQ_CTRL_WORDS; k++) ctrl[k] = 0;
+            *done = 0;
+            __threadfence_system();
+        }
+    }
 }
 
 size_t units_lds_bytes(const StripPlan &plan, int nb)
@@ -905,9 +1006,9 @@ hipError_t launch_plan_pass(const DevLayout &L, const StartDesc *starts, const i
 hipError_t launch_sweep_units(const DevLayout &L, const float *v, const StartDesc *starts,
                               const int4 *lists, int list_cap, int *ctrl, int nblocks,
                               int *changed, const StripCol *cols, const StripPlan &plan,
-                              int parity, hipStream_t st)
+                              int parity, const UnitPassTail &tail, hipStream_t st)
 {
-    if (nblocks <= 0) return hipSuccess;
+    if (nblocks <= 0) return hipErrorInvalidValue;      // the last workgroup closes the pass
     const int btiles = strip_btiles(L);
     auto kern = sweep_units_kernel<STRIP_K>;
     const size_t lds = units_lds_bytes(plan, L.n[1]);
@@ -917,70 +1018,7 @@ hipError_t launch_sweep_units(const DevLayout &L, const float *v, const StartDes
         if (e != hipSuccess) return e;
     }
     hipLaunchKernelGGL(kern, dim3((unsigned)nblocks), dim3(STRIP_TB, STRIP_NS), lds, st, L, v, starts,
-                       lists, list_cap, ctrl, changed, cols, plan, btiles, strip_cstrips(L), parity);
-    return hipGetLastError();
-}
-
-// ===========================================================================
-// exact relaxation of the few cells that own a dead edge: one wave per cell
-// ===========================================================================
-// Lanes split the pull entries, apply the full liveness rule, and reduce their
-// minima across the wave.  Same in-place, single-writer contract as the other
-// kernels: only this kernel ever stores into the cells of a start's box.
-
-__global__ void __launch_bounds__(64)
-sweep_special_kernel(DevLayout L, const float *__restrict__ v,
-                     const StartDesc *__restrict__ starts, const int *__restrict__ active,
-                     int *__restrict__ changed, const CellEntry *__restrict__ entries,
-                     int nentries, int max_box_cells, int parity)
-{
-    const int s = active[blockIdx.x / max_box_cells];
-    int cell = blockIdx.x % max_box_cells;
-    const StartDesc sd = starts[s];
-    const int ea = sd.box_hi[0] - sd.box_lo[0] + 1;
-    const int eb = sd.box_hi[1] - sd.box_lo[1] + 1;
-    const int ec = sd.box_hi[2] - sd.box_lo[2] + 1;
-    if (ea <= 0 || eb <= 0 || ec <= 0 || cell >= ea * eb * ec) return;
-    const int c = sd.box_lo[2] + cell % ec; cell /= ec;
-    const int b = sd.box_lo[1] + cell % eb; cell /= eb;
-    const int a = sd.box_lo[0] + cell;
-
-    float *__restrict__ T = sd.T;
-    const long long ci = dev_index(L, a, b, c);
-    const bool c_is_start = (ci == sd.sidx);
-    const float vc = v[ci];
-    const float told = T[ci];
-    float best = told;
-    for (int e = threadIdx.x; e < nentries; e += 64) {
-        const CellEntry en = entries[e];
-        const long long oi = ci + en.delta;
-        const bool live = ((en.flags & PULL_FWD) && !c_is_start)
-                       || ((en.flags & PULL_REV) && oi != sd.sidx);
-        const float sum = vc + v[oi];
-        const float delay = en.h * sum;
-        const float cand = delay + T[oi];
-        if (live && cand < best) best = cand;
-    }
-#pragma unroll
-    for (int w = 32; w >= 1; w >>= 1) best = fminf(best, __shfl_xor(best, w));
-    if (threadIdx.x == 0 && best < told) {
-        T[ci] = best;
-        atomicOr(&changed[s], 1);
-        // runs after the unit pass of the same parity has written its flags
-        const int btiles = strip_btiles(L), cstrips = strip_cstrips(L);
-        const int nunits = strip_units(L);
-        sd.tile_flags[parity * nunits + (a * btiles + b / STRIP_TB) * cstrips + c / STRIP_K] = 7;
-    }
-}
-
-hipError_t launch_sweep_special(const DevLayout &L, const float *v, const StartDesc *starts,
-                                const int *active, int nactive, int *changed,
-                                const CellEntry *entries, int nentries, int max_box_cells,
-                                int parity, hipStream_t st)
-{
-    if (nactive <= 0 || max_box_cells <= 0) return hipSuccess;
-    hipLaunchKernelGGL(sweep_special_kernel, dim3((unsigned)(nactive * max_box_cells)), dim3(64), 0,
-                       st, L, v, starts, active, changed, entries, nentries, max_box_cells, parity);
+                       lists, list_cap, ctrl, changed, cols, plan, btiles, strip_cstrips(L), parity, tail);
     return hipGetLastError();
 }
 
