@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define TTSWEEP_ABI_VERSION 1
+#define TTSWEEP_ABI_VERSION 2
 
 /* Forward-star entry: same layout as `struct FS`
  * (serial_new/sweep-tt-multistart.c:46-49).  d must already hold
@@ -125,14 +125,22 @@ int ttsweep_solve_device(ttsweep_ctx *ctx, int nstart, const ttsweep_start *star
 int ttsweep_get_stats(const ttsweep_ctx *ctx, ttsweep_stats *out);
 
 /* On-device fixed-point check in the spirit of testconvergence
- * (old/wavefront-openmp/wave-multistart.c:300-347) on serial_new's edge set: counts
- * the (cell, offset) pairs through which one more reference sweep would still store
- * (serial_new/...:219-249, evaluated without modifying the box) and the cells still at
- * INFINITY.  Both are 0 for a converged box.  tt_dev: device memory, FLOATBOX layout.
- * For grids where no CPU oracle run is feasible (one reference sweep of 1024x1024x512
- * takes ~40 min).  Returns 0 on success, < 0 on error. */
+ * (old/wavefront-openmp/wave-multistart.c:300-347) on serial_new's edge set:
+ *   open_edges         (cell, offset) pairs through which one more reference sweep would
+ *                      still store (serial_new/...:219-249, evaluated without modifying
+ *                      the box): 0 iff nothing can improve any more;
+ *   cells_infinite     cells still at INFINITY;
+ *   cells_unsupported  cells (other than the start) whose travel time is smaller than
+ *                      every candidate their live edges offer, i.e. that no store of
+ *                      :222-223 / :246-247 can have produced: 0 iff nothing is too small.
+ * open_edges == 0 and cells_unsupported == 0 together pin the box to the one fixed point
+ * of the relaxation (all delays positive), which is what the reference's loop :151-170
+ * converges to.  tt_dev: device memory, FLOATBOX layout.  For grids where no CPU oracle
+ * run is feasible (one reference sweep of 1024x1024x512 takes ~40 min).  Any of the
+ * three result pointers may be NULL.  Returns 0 on success, < 0 on error. */
 int ttsweep_validate_device(ttsweep_ctx *ctx, const ttsweep_start *start, const float *tt_dev,
-                            long long *open_edges, long long *cells_infinite);
+                            long long *open_edges, long long *cells_infinite,
+                            long long *cells_unsupported);
 
 /* Multi-GPU form of ttsweep_solve for a host program: the start points are
  * independent (serial_new/...:158-162; mpi/backup.c:351-363 runs one start per

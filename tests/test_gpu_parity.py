@@ -266,7 +266,9 @@ def sampled_open_edges(v, tt, offs, start, nsample, seed):
 def test_device_validator_matches_oracle_validator(P, golden24, oracle):
     """ttsweep_validate_device counts exactly what the oracle's validator counts: 0 on
     converged boxes, the same positive numbers on the reference's one- and two-pass
-    states (818-FS and the non-symmetric star)."""
+    states (818-FS and the non-symmetric star).  Its third count (cells no store can have
+    produced) is 0 on every state the reference passes through and > 0 on a box with a
+    value that is too small."""
     import torch
     dev = torch.device("cuda:0")
     for sname in ("818", "nonsym"):
@@ -280,8 +282,15 @@ def test_device_validator_matches_oracle_validator(P, golden24, oracle):
             for tt in (conv, golden24.z[f"pass1_{sname}"], golden24.z[f"pass2_{sname}"]):
                 want = oracle.validate(golden24.v, tt, ofs, start)
                 got = sol.validate_device(start, torch.from_numpy(np.ascontiguousarray(tt)).to(dev))
-                assert got == want, (sname, got, want)
-            assert sol.validate_device(start, torch.from_numpy(conv).to(dev)) == (0, 0)
+                assert got[:2] == want and got[2] == 0, (sname, got, want)
+            assert sol.validate_device(start, torch.from_numpy(conv).to(dev)) == (0, 0, 0)
+            # a value below the fixed point: its neighbours can now improve (open edges) and
+            # nothing supports the value itself
+            bad = conv.copy()
+            far = tuple(0 if 2 * s >= n else n - 1 for s, n in zip(start, conv.shape))
+            bad[far] = np.float32(0.5) * bad[far]
+            opened, _, unsupported = sol.validate_device(start, torch.from_numpy(bad).to(dev))
+            assert opened > 0 and unsupported >= 1, (sname, opened, unsupported)
 
 
 def test_sampled_checker_detects_unconverged_state(P, golden24, oracle):
@@ -315,13 +324,38 @@ def test_512_grid_properties(P):
             assert sol.solve_device(starts, tt, init=True) == 1
             if kernel == 2:
                 assert sol.solve_device(starts, tt, init=False) == 0
-                assert sol.validate_device(starts[0], tt[0]) == (0, 0)      # every cell, on the device
+                assert sol.validate_device(starts[0], tt[0]) == (0, 0, 0)   # every cell, on the device
             out[kernel] = tt[0].cpu().numpy()
     assert np.array_equal(out[1].view(np.uint32), out[2].view(np.uint32))
     tt = out[2]
     assert np.isfinite(tt).all() and tt[tuple(starts[0])] == 0 and (tt >= 0).all()
     v = v_dev.cpu().numpy()
     assert sampled_open_edges(v, tt, offs, starts[0], 20000, 2) == 0
+
+
+def test_volume_above_2_gib(P):
+    """818-FS on 1024x1024x512 (padded volumes of 2.3 GB: byte offsets beyond 2^31 inside one
+    volume).  No second implementation is fast enough here, so the box is pinned by the
+    device validator alone: nothing can improve and nothing is too small, i.e. it is the
+    fixed point; plus the size-independent properties (start 0, finite, non-negative, a
+    second solve changes nothing)."""
+    import torch
+    shape = (1024, 1024, 512)
+    dev = torch.device("cuda:0")
+    v_dev = P.inputs.velocity_model_device(*shape, 20160507, dev)
+    fs = P.inputs.make_fs(P.inputs.read_triples(P.inputs.star_path("818")))
+    starts = P.inputs.scaled_starts(P.inputs.read_triples(P.inputs.starts_path("24")), *shape)[:1]
+    with P.TravelTimeSolver(shape, fs) as sol:
+        sol.set_velocity(v_dev)
+        tt = torch.empty((1,) + shape, dtype=torch.float32, device=dev)
+        assert sol.solve_device(starts, tt, init=True) == 1
+        assert sol.stats()["kernel_variant"] == 2
+        assert sol.validate_device(starts[0], tt[0]) == (0, 0, 0)
+        assert float(tt[0][tuple(starts[0])]) == 0.0
+        assert bool(torch.isfinite(tt).all()) and float(tt.min()) == 0.0
+        before = tt.clone()
+        assert sol.solve_device(starts, tt, init=False) == 0
+        assert torch.equal(before.view(torch.int32), tt.view(torch.int32))
 
 
 def test_solve_multi_shards_starts_over_devices(P, golden24):

@@ -52,7 +52,8 @@ SYMBOLS = [
     ("ttsweep_solve", C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     ("ttsweep_solve_device", C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int]),
     ("ttsweep_get_stats", C.c_int, [C.c_void_p, C.c_void_p]),
-    ("ttsweep_validate_device", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    ("ttsweep_validate_device", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                         C.c_void_p]),
     ("ttsweep_solve_multi", C.c_int, [C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p,
                                       C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     ("ttsweep_sweepXYZ", C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p,

@@ -91,6 +91,7 @@ struct ttsweep_ctx {
     int *d_unitq_ctrl = nullptr;            // UNITQ_CTRL_WORDS (counts, cursors)
     int unitq_blocks = 0;                   // persistent grid: workgroups the device holds at once
     std::vector<std::vector<int>> unit_order;       // per start: unit ids, nearest to the start first
+    std::vector<long long> unit_order_key;          // start cell the cached order belongs to
     // Distance gate (see sweep_strip_kernel): radius of the first pass and cells it opens per
     // pass.  Defaults follow the star's reach: final values spread at about half the reach
     // per pass (measured, 818-offset star: 3.5 cells/pass gives the shortest solve).
@@ -200,12 +201,7 @@ static void make_layout_strip(ttsweep_ctx *ctx)
 // Can the STRIP kernel handle this star?  (plane and strip offsets within +-7)
 static bool strip_supported(const ttsweep_ctx *ctx)
 {
-    if (ctx->pull.empty() || ctx->radius > STRIP_MAX_RA || ctx->radius >= STRIP_CF) return false;
-    // the slab loads address the padded volume with 32-bit byte offsets: keep it below 4 GiB
-    // (bound on the padded extents: halo + rounding to whole lane tiles / strips)
-    const double padded = (double)(ctx->nx + 2 * STRIP_MAX_RA + STRIP_TB) * (ctx->ny + 2 * STRIP_MAX_RA + STRIP_TB)
-                        * (ctx->nz + 2 * STRIP_MAX_RA + STRIP_TB);
-    return padded * sizeof(float) < 4294967296.0;
+    return !ctx->pull.empty() && ctx->radius <= STRIP_MAX_RA && ctx->radius < STRIP_CF;
 }
 
 static int upload_strip_plan(ttsweep_ctx *ctx)
@@ -407,6 +403,7 @@ static int timed_event(ttsweep_ctx *ctx, hipEvent_t *out)
 // instead of one tile per pass.  Correctness never depends on this order.
 static int build_worklist(ttsweep_ctx *ctx, int nactive)
 {
+    const auto t_begin = std::chrono::steady_clock::now();
     const int nunits = strip_units(ctx->L);
     constexpr int NX = UNITQ_LISTS;
     std::vector<std::vector<int2>> per_xcd(NX);
@@ -457,6 +454,9 @@ static int build_worklist(ttsweep_ctx *ctx, int nactive)
         const int wgs = 3 * std::max(prop.multiProcessorCount, 1);     // 3 workgroups (12 waves) per CU
         ctx->unitq_blocks = ((wgs + UNITQ_LISTS - 1) / UNITQ_LISTS) * UNITQ_LISTS;
     }
+    if (getenv("TTSWEEP_TRACE"))
+        fprintf(stderr, "ttsweep work list for %d starts: %.0f us\n", nactive,
+                std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_begin).count());
     return 0;
 }
 
@@ -674,6 +674,7 @@ int ttsweep_set_option(ttsweep_ctx *ctx, int key, long long value)
         if (ctx->d_T) HIPCHK(hipFree(ctx->d_T));
         ctx->d_T = nullptr;
         ctx->capacity_starts = 0;
+        ctx->unit_order_key.assign(ctx->unit_order_key.size(), -1);     // orders belong to the old layout
         HIPCHK(hipMalloc((void **)&ctx->d_v, (size_t)ctx->L.cells * sizeof(float)));
         if (upload_star(ctx)) return -1;
         if (k == TTSWEEP_KERNEL_STRIP && upload_strip_plan(ctx)) return -1;
@@ -756,12 +757,23 @@ int ttsweep_solve_device(ttsweep_ctx *ctx, int nstart, const ttsweep_start *star
         sd.work = ctx->d_work + 3 * s;
         if (init) HIPCHK(launch_init_tt(L, sd.T, sd.sidx, ctx->stream));
         else HIPCHK(launch_pack(L, tt_dev[s], sd.T, INFINITY, ctx->stream));
-        if (ctx->kernel == TTSWEEP_KERNEL_STRIP) {
+        if (ctx->kernel == TTSWEEP_KERNEL_STRIP)
             HIPCHK(launch_init_tile_flags(L, sd, /*from_box=*/!init, ctx->stream));
-            if ((int)ctx->unit_order.size() < nstart) ctx->unit_order.resize(nstart);
-            order_units(ctx, sd, ctx->unit_order[s]);
-        }
         ctx->h_active[s] = s;
+    }
+    if (ctx->kernel == TTSWEEP_KERNEL_STRIP) {
+        // host work while the device initialises the boxes: every start's units, nearest
+        // first (kept from the previous solve when the start point is the same)
+        if ((int)ctx->unit_order.size() < nstart) {
+            ctx->unit_order.resize(nstart);
+            ctx->unit_order_key.resize(nstart, -1);
+        }
+        for (int s = 0; s < nstart; s++) {
+            const StartDesc &sd = ctx->h_starts[s];
+            if (ctx->unit_order_key[s] == sd.sidx && !ctx->unit_order[s].empty()) continue;
+            order_units(ctx, sd, ctx->unit_order[s]);
+            ctx->unit_order_key[s] = sd.sidx;
+        }
     }
     HIPCHK(hipMemcpyAsync(ctx->d_starts, ctx->h_starts, nstart * sizeof(StartDesc),
                           hipMemcpyHostToDevice, ctx->stream));
@@ -948,7 +960,8 @@ int ttsweep_solve(ttsweep_ctx *ctx, int nstart, const ttsweep_start *starts,
 }
 
 int ttsweep_validate_device(ttsweep_ctx *ctx, const ttsweep_start *start, const float *tt_dev,
-                            long long *open_edges, long long *cells_infinite)
+                            long long *open_edges, long long *cells_infinite,
+                            long long *cells_unsupported)
 {
     if (!ctx || !start || !tt_dev) return set_error("null argument");
     if (!ctx->have_v) return set_error("velocity not set");
@@ -961,15 +974,16 @@ int ttsweep_validate_device(ttsweep_ctx *ctx, const ttsweep_start *start, const 
     const int u[3] = {start->i, start->j, start->k};
     const long long sidx = dev_index(L, u[L.perm[0]], u[L.perm[1]], u[L.perm[2]]);
     unsigned long long *d_counts = ctx->d_work;     // first words of the per-solve counters
-    HIPCHK(hipMemsetAsync(d_counts, 0, 2 * sizeof(unsigned long long), ctx->stream));
+    HIPCHK(hipMemsetAsync(d_counts, 0, 3 * sizeof(unsigned long long), ctx->stream));
     HIPCHK(launch_pack(L, tt_dev, ctx->d_T, INFINITY, ctx->stream));
     HIPCHK(launch_validate(L, ctx->d_v, ctx->d_T, sidx, ctx->d_fwd_entries, ctx->n_fwd_entries,
-                           d_counts, ctx->stream));
-    unsigned long long h[2] = {0, 0};
+                           ctx->d_cell_entries, ctx->n_cell_entries, d_counts, ctx->stream));
+    unsigned long long h[3] = {0, 0, 0};
     HIPCHK(hipMemcpyAsync(h, d_counts, sizeof h, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
     if (open_edges) *open_edges = (long long)h[0];
     if (cells_infinite) *cells_infinite = (long long)h[1];
+    if (cells_unsupported) *cells_unsupported = (long long)h[2];
     return 0;
 }
 

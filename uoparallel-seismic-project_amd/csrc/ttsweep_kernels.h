@@ -26,10 +26,11 @@ hipError_t launch_sweep_cell(const DevLayout &L, const float *v, const StartDesc
                              const CellEntry *entries, int nentries, hipStream_t st);
 
 // ---- validator: counts[0] += (cell, forward entry) pairs a reference sweep would still
-// store through, counts[1] += cells still at +INFINITY (T is one padded volume)
+// store through, counts[1] += cells still at +INFINITY, counts[2] += cells whose travel
+// time no live edge can have produced (T is one padded volume)
 hipError_t launch_validate(const DevLayout &L, const float *v, const float *T, long long sidx,
-                           const FwdEntry *entries, int nentries, unsigned long long *counts,
-                           hipStream_t st);
+                           const FwdEntry *entries, int nentries, const CellEntry *cell_entries,
+                           int ncell_entries, unsigned long long *counts, hipStream_t st);
 
 // ---- sweep, variant STRIP --------------------------------------------------
 // Same contract as launch_sweep_cell, but cells inside a start's dead-edge box

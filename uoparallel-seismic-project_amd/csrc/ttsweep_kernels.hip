@@ -234,9 +234,49 @@ validate_kernel(DevLayout L, const float *__restrict__ v, const float *__restric
     }
 }
 
+// counts[2] += cells (other than the start) whose finite travel time is SMALLER than every
+// candidate their live edges offer: no edge can have produced it.  Together with
+// counts[0] == 0 (no edge can still improve anything) this pins T to the one fixed point of
+// the relaxation, i.e. to the reference's converged result.  One thread per cell, the whole
+// pull star with the liveness rule of sweep_cell_kernel.
+__global__ void __launch_bounds__(CELL_BX *CELL_BY)
+support_kernel(DevLayout L, const float *__restrict__ v, const float *__restrict__ T,
+               long long sidx, const CellEntry *__restrict__ entries, int nentries,
+               unsigned long long *__restrict__ counts, int cblocks, int bblocks)
+{
+    unsigned bid = blockIdx.x;
+    const int cb = bid % cblocks; bid /= cblocks;
+    const int bb = bid % bblocks; bid /= bblocks;
+    const int a = bid;
+    const int c = cb * CELL_BX + threadIdx.x;
+    const int b = bb * CELL_BY + threadIdx.y;
+    unsigned unsupported = 0;
+    if (c < L.n[2] && b < L.n[1]) {
+        const long long ci = dev_index(L, a, b, c);
+        const float vc = v[ci], tc = T[ci];
+        if (ci != sidx && tc < __builtin_inff()) {
+            float best = __builtin_inff();
+            for (int e = 0; e < nentries; e++) {
+                const CellEntry en = entries[e];
+                const long long oi = ci + en.delta;
+                // (ci is not the start, so PULL_FWD entries are live)
+                const bool live = (en.flags & PULL_FWD) || ((en.flags & PULL_REV) && oi != sidx);
+                const float sum = vc + v[oi];
+                const float delay = en.h * sum;
+                const float cand = delay + T[oi];
+                if (live && cand < best) best = cand;
+            }
+            unsupported = tc < best;
+        }
+    }
+#pragma unroll
+    for (int w = 32; w >= 1; w >>= 1) unsupported += __shfl_xor(unsupported, w);
+    if ((threadIdx.x & 63) == 0 && unsupported) atomicAdd(&counts[2], (unsigned long long)unsupported);
+}
+
 hipError_t launch_validate(const DevLayout &L, const float *v, const float *T, long long sidx,
-                           const FwdEntry *entries, int nentries, unsigned long long *counts,
-                           hipStream_t st)
+                           const FwdEntry *entries, int nentries, const CellEntry *cell_entries,
+                           int ncell_entries, unsigned long long *counts, hipStream_t st)
 {
     const int cblocks = (L.n[2] + CELL_BX - 1) / CELL_BX;
     const int bblocks = (L.n[1] + CELL_BY - 1) / CELL_BY;
@@ -245,6 +285,8 @@ hipError_t launch_validate(const DevLayout &L, const float *v, const float *T, l
     if (nblocks > 0x7fffffffLL) return hipErrorInvalidValue;
     hipLaunchKernelGGL(validate_kernel, dim3((unsigned)nblocks), dim3(CELL_BX, CELL_BY), 0, st, L, v,
                        T, sidx, entries, nentries, counts, cblocks, bblocks);
+    hipLaunchKernelGGL(support_kernel, dim3((unsigned)nblocks), dim3(CELL_BX, CELL_BY), 0, st, L, v,
+                       T, sidx, cell_entries, ncell_entries, counts, cblocks, bblocks);
     return hipGetLastError();
 }
 
@@ -658,22 +700,23 @@ __device__ __forceinline__ void relax_special_cell(const DevLayout &L, const flo
 __device__ __forceinline__ int slab_swizzle(int row) { return (row >> 1) & 7; }
 
 //
-// The loads are buffer loads: the (wave-uniform) position of the slab and of the 8-row group
-// goes into the scalar offset, so the per-lane byte offset is the same few values for every
-// plane and group and costs no address arithmetic per instruction.  Offsets are 32-bit: the
-// padded volume must stay below 4 GiB (checked on the host).
+// The loads are buffer loads whose resource starts at the slab's first element (a 64-bit
+// scalar add per plane and array): the 8-row group goes into the scalar offset, the per-lane
+// byte offset is the same few values for every plane and group, so an instruction costs no
+// vector address arithmetic, and all offsets stay far below 2^31 whatever the volume size.
 typedef __amdgpu_buffer_rsrc_t buf_rsrc;
 
 __device__ __forceinline__ buf_rsrc make_rsrc(const float *base)
 {
     // raw buffer, no stride, no range limit; word 3 as for gfx90a/gfx94x/gfx950 raw buffers
-    return __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(base), 0, 0x7fffffff, 0x00020000);
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(base), 0, 0xffffffff, 0x00020000);
 }
 
-__device__ __forceinline__ void stage_slab(buf_rsrc rv, buf_rsrc rt, unsigned src_bytes,
+__device__ __forceinline__ void stage_slab(const float *__restrict__ v_slab, const float *__restrict__ t_slab,
                                            unsigned s1_bytes, float *slab, int rows, int rows8,
                                            int wave, int lane)
 {
+    const buf_rsrc rv = make_rsrc(v_slab), rt = make_rsrc(t_slab);
     const int ninstr = rows8 / 8;           // wave-instructions per array
     const int rloc = lane >> 3, p = lane & 7;
     // row r = 8 kk + rloc has swizzle ((r >> 1) & 7) = (rloc >> 1) ^ (4 (kk & 1))
@@ -686,7 +729,7 @@ __device__ __forceinline__ void stage_slab(buf_rsrc rv, buf_rsrc rt, unsigned sr
         unsigned voff = (kk & 1) ? voff_odd : voff_even;
         if (kk == ninstr - 1)               // rows past the slab re-read its last row
             voff -= (unsigned)max(kk * 8 + rloc - (rows - 1), 0) * s1_bytes;
-        const unsigned soff = src_bytes + (unsigned)(kk * 8) * s1_bytes;
+        const unsigned soff = (unsigned)(kk * 8) * s1_bytes;
         float *dst = slab + (is_t ? SLAB_T_BYTES / 4 : 0) + kk * (8 * STRIP_W);     // wave-uniform
         __builtin_amdgcn_raw_ptr_buffer_load_lds(is_t ? rt : rv, (__attribute__((address_space(3))) void *)dst,
                                                  16, (int)voff, (int)soff, 0, 0);
@@ -759,8 +802,6 @@ sweep_units_kernel(DevLayout L, const float *__restrict__ v, const StartDesc *__
     }
     __syncthreads();
 
-    const buf_rsrc rv = make_rsrc(v);
-
     // ---- the dead-edge cells of the active starts, one wave per cell
     for (int w = blockIdx.x * NS + wave; w < tail.nactive * tail.max_box_cells; w += gridDim.x * NS) {
         const int s = tail.active[w / tail.max_box_cells];
@@ -815,15 +856,14 @@ sweep_units_kernel(DevLayout L, const float *__restrict__ v, const StartDesc *__
         // ---- planes to relax, in order; the first one starts to load right away.  Slab of
         // plane a+da: rows b0-rb .. b0+63+rb, columns c0-CF .. c0+K+CF-1.
         unsigned todo = my_planes & plane_mask;
-        const unsigned src0 = (unsigned)(((long long)(a - plan.ra + L.lo[0]) * L.s0
-                                          + (long long)(b0 - rb + L.lo[1]) * L.s1
-                                          + (c0 - STRIP_CF + L.lo[2])) * 4);          // bytes
-        const unsigned s0_bytes = (unsigned)(L.s0 * 4), s1_bytes = (unsigned)(L.s1 * 4);
-        const buf_rsrc rt = make_rsrc(T);
+        const long long src0 = (long long)(a - plan.ra + L.lo[0]) * L.s0
+                             + (long long)(b0 - rb + L.lo[1]) * L.s1 + (c0 - STRIP_CF + L.lo[2]);
+        const unsigned s1_bytes = (unsigned)(L.s1 * 4);
         int buf = 0;
-        if (todo)
-            stage_slab(rv, rt, src0 + (unsigned)__builtin_ctz(todo) * s0_bytes, s1_bytes, slabs, rows,
-                       rows8, wave, lane);
+        if (todo) {
+            const long long src = src0 + (long long)__builtin_ctz(todo) * L.s0;
+            stage_slab(v + src, T + src, s1_bytes, slabs, rows, rows8, wave, lane);
+        }
         // descriptor of the first column this wave will relax (later ones are requested one
         // column ahead, across plane boundaries)
         ColRegs cur = load_col(cols, min(__builtin_amdgcn_readfirstlane(col_range[wave * 16 + (todo ? __builtin_ctz(todo) : 0)]) & 0xffff,
@@ -863,9 +903,10 @@ sweep_units_kernel(DevLayout L, const float *__restrict__ v, const StartDesc *__
             __syncthreads();
             PROF_T(t1);
             // the next plane loads into the other slab while this one is relaxed
-            if (todo)
-                stage_slab(rv, rt, src0 + (unsigned)__builtin_ctz(todo) * s0_bytes, s1_bytes,
-                           slabs + (buf ^ 1) * slab_floats, rows, rows8, wave, lane);
+            if (todo) {
+                const long long src = src0 + (long long)__builtin_ctz(todo) * L.s0;
+                stage_slab(v + src, T + src, s1_bytes, slabs + (buf ^ 1) * slab_floats, rows, rows8, wave, lane);
+            }
             PROF_T(t2);
 #ifdef TTSWEEP_PROFILE
             p_wait += t1 - t0; p_stage += t2 - t1;

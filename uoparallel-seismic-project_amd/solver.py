@@ -142,17 +142,18 @@ class TravelTimeSolver:
                       "ttsweep_solve_device")
 
     def validate_device(self, start, tt):
-        """(open_edges, cells_infinite) of one box in HBM (torch tensor [nx,ny,nz]):
-        the reference's store conditions evaluated on the device; (0, 0) when converged."""
+        """(open_edges, cells_infinite, cells_unsupported) of one box in HBM (torch tensor
+        [nx,ny,nz]): the reference's store conditions evaluated on the device, and the cells
+        no store can have produced; (0, 0, 0) exactly for the converged box."""
         import torch
         assert tt.is_cuda and tt.dtype == torch.float32 and tt.is_contiguous()
         assert tuple(tt.shape) == self.shape
         torch.cuda.current_stream(tt.device).synchronize()
         st = Start(int(start[0]), int(start[1]), int(start[2]))
-        a, b = C.c_longlong(0), C.c_longlong(0)
+        a, b, c = C.c_longlong(0), C.c_longlong(0), C.c_longlong(0)
         _check(self._L.ttsweep_validate_device(self._ctx, C.byref(st), tt.data_ptr(), C.byref(a),
-                                               C.byref(b)), "ttsweep_validate_device")
-        return a.value, b.value
+                                               C.byref(b), C.byref(c)), "ttsweep_validate_device")
+        return a.value, b.value, c.value
 
     def stats(self) -> dict:
         st = Stats()
