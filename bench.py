@@ -17,8 +17,9 @@ fixed total work); inputs are resident in HBM when the timed region starts.
 metric: Mcells*sweeps/s = (cells relaxed against the whole forward star, summed
 over passes and starts) / wall seconds / 1e6; one full sweep of one start relaxes
 `cells` cells, so for a schedule that skips nothing this is cells x sweeps / s.
-The GPU schedule skips tiles whose inputs did not change, so it executes fewer
-cell-relaxations than full sweeps would; those skipped cells are NOT counted.
+The GPU schedule skips units whose inputs did not change and holds far units back until
+final values can reach them, so it executes fewer cell-relaxations than full sweeps
+would; those skipped cells are NOT counted.
 Passes of different schedules are the same work per cell but not the same
 progress, so ms_per_step (time to the converged solution) is the number to
 compare across schedules and against the CPU.
@@ -149,7 +150,7 @@ def main():
         step()
     fence()
     t0 = time.perf_counter()
-    sweeps_local = 0            # passes launched (a pass may skip inactive tiles)
+    sweeps_local = 0            # passes launched (a pass relaxes only the units that are due)
     relaxed_local = 0           # cells actually relaxed against the whole star
     for _ in range(args.steps):
         step()
