@@ -354,9 +354,13 @@ __device__ __forceinline__ void pin_col(ColRegs &r)
                    "+s"(r.h[13]), "+s"(r.h[14]), "+s"(r.h[15]));
 }
 
-// Activity flag bits of a unit (tile_flags): something improved at all / within the
-// first / the last CF-1 cells of the strip (the only cells a neighbouring strip reads).
-enum : int { FLAG_ANY = 1, FLAG_LO = 2, FLAG_HI = 4 };
+// Activity flag word of a unit (tile_flags): where something improved, as seen by the
+// neighbour that would read it.  Along the strip axis c and along the lane axis b a zone is
+// ANY (anywhere), LO or HI (within reach of the unit's low / high border: the only cells a
+// neighbouring strip or lane tile reads); bit 3 * zone_b + zone_c is set when a cell in that
+// combination of zones improved.
+enum : int { ZONE_ANY = 0, ZONE_LO = 1, ZONE_HI = 2, FLAG_ALL = 0x1ff };
+__host__ __device__ constexpr int flag_bit(int zone_b, int zone_c) { return 1 << (3 * zone_b + zone_c); }
 
 // Relax all offsets dc of one (da, db) column: load the neighbour window from LDS into
 // registers once, then fold every present offset into acc.  row: start of the lane's slab
@@ -496,7 +500,7 @@ init_tile_flags_kernel(int *__restrict__ flags, int nunits, int start_unit)
     const int t = blockIdx.x * 256 + threadIdx.x;
     if (t >= nunits) return;
     flags[t] = 0;
-    flags[nunits + t] = t == start_unit ? 7 : 0;
+    flags[nunits + t] = t == start_unit ? FLAG_ALL : 0;
     flags[2 * nunits + t] = 0;          // pend[]: nothing held back yet
     if (t == 0) flags[3 * nunits] = 1;  // one source unit: the distance gate applies
 }
@@ -521,7 +525,7 @@ init_tile_flags_box_kernel(DevLayout L, const float *__restrict__ T, int *__rest
     const bool any = __ballot(finite) != 0ull;
     if (lane == 0) {
         flags[blockIdx.x] = 0;
-        flags[nunits + blockIdx.x] = any ? 7 : 0;
+        flags[nunits + blockIdx.x] = any ? FLAG_ALL : 0;
         flags[2 * nunits + blockIdx.x] = 0;
         if (any) atomicAdd(&flags[3 * nunits], 1);      // number of source units
     }
@@ -552,8 +556,8 @@ hipError_t launch_init_tile_flags(const DevLayout &L, const StartDesc &sd, bool 
 // Activity tracking.  A unit's offsets with plane offset da have to be relaxed in a pass
 // only if a unit they read from (plane a+da, +-1 lane tile, +-1 strip) improved in the
 // previous pass: everything else was already relaxed against unchanged values.  Every
-// unit has a flag word per pass parity (FLAG_* bits: something improved at all / within
-// reach of the strip's low / high border).
+// unit has a flag word per pass parity (where it improved, by border zone: see flag_bit), so
+// that a neighbouring strip or lane tile reacts only to improvements within its reach.
 //
 // Distance gate.  Far from the start the first values to arrive (over long edges) are
 // poor and get refined pass after pass; relaxing those units early is wasted work.  A unit
@@ -605,7 +609,9 @@ plan_pass_kernel(DevLayout L, const StartDesc *__restrict__ starts, const int2 *
             bool due = false;
             for (int r = 0; r < 9; r++) {
                 const int nb = bt + r / 3 - 1, nc = cs + r % 3 - 1;
-                const int need = (r % 3 == 0) ? FLAG_HI : (r % 3 == 2) ? FLAG_LO : FLAG_ANY;
+                // the neighbour below / before reads across our low border: its HI zone matters
+                const int need = flag_bit(r / 3 == 0 ? ZONE_HI : r / 3 == 2 ? ZONE_LO : ZONE_ANY,
+                                          r % 3 == 0 ? ZONE_HI : r % 3 == 2 ? ZONE_LO : ZONE_ANY);
                 if (nb >= 0 && nb < btiles && nc >= 0 && nc < cstrips
                     && (prev_flags[(na * btiles + nb) * cstrips + nc] & need))
                     due = true;
@@ -686,7 +692,7 @@ __device__ __forceinline__ void relax_special_cell(const DevLayout &L, const flo
         T[ci] = best;
         atomicOr(&changed[s], 1);
         const int btiles = strip_btiles(L), cstrips = strip_cstrips(L);
-        atomicOr(sd.tile_flags + parity * strip_units(L) + (a * btiles + b / STRIP_TB) * cstrips + c / STRIP_K, 7);
+        atomicOr(sd.tile_flags + parity * strip_units(L) + (a * btiles + b / STRIP_TB) * cstrips + c / STRIP_K, FLAG_ALL);
     }
 }
 
@@ -961,6 +967,9 @@ sweep_units_kernel(DevLayout L, const float *__restrict__ v, const StartDesc *__
         const bool row_ok = lane < tb_eff && b < L.n[1];
         const bool in_box_ab = a >= sd.box_lo[0] && a <= sd.box_hi[0] && b >= sd.box_lo[1] && b <= sd.box_hi[1];
         int improved = 0;
+        // zones of this lane's row along b (3 bits: ANY, LO, HI), spread to the b positions
+        // of the flag word: zone set Zc of a cell becomes Zc | Zc << 3 (LO) | Zc << 6 (HI)
+        const int zb_lo = lane < rb, zb_hi = lane >= STRIP_TB - rb;
 #pragma unroll
         for (int qq = 0; qq < CQ; qq++) {
             const int cq = q0 + qq;
@@ -968,7 +977,8 @@ sweep_units_kernel(DevLayout L, const float *__restrict__ v, const StartDesc *__
             const bool special = in_box_ab && c >= sd.box_lo[2] && c <= sd.box_hi[2];
             if (row_ok && c < L.n[2] && !special && best[qq] < T[own + cq]) {
                 T[own + cq] = best[qq];
-                improved |= FLAG_ANY | (cq < STRIP_CF - 1 ? FLAG_LO : 0) | (cq > K - STRIP_CF ? FLAG_HI : 0);
+                const int zc = 1 | (cq < STRIP_CF - 1 ? 2 : 0) | (cq > K - STRIP_CF ? 4 : 0);
+                improved |= zc | (zb_lo ? zc << 3 : 0) | (zb_hi ? zc << 6 : 0);
             }
         }
 #pragma unroll
