@@ -129,11 +129,14 @@ def test_sweepXYZ_dropin(P, golden24):
 
 
 @pytest.mark.parametrize("shape,seed", [((33, 70, 19), 11), ((70, 33, 40), 12), ((5, 4, 3), 13),
-                                        ((1, 1, 1), 14), ((2, 300, 2), 15), ((130, 3, 66), 16)])
+                                        ((1, 1, 1), 14), ((2, 300, 2), 15), ((130, 3, 66), 16),
+                                        ((70, 66, 130), 17), ((65, 129, 67), 18)])
 @pytest.mark.parametrize("kernel", KERNELS)
 def test_seeded_random_vs_oracle(P, oracle, shape, seed, kernel):
-    """Ragged / tiny / thin grids (smaller than the star radius on some axes) with
-    random velocities and a random asymmetric star, against the CPU oracle."""
+    """Ragged / tiny / thin grids (smaller than the star radius on some axes), and grids
+    with every axis above 64 (several lane tiles per plane: the border zones of the
+    activity flags), with random velocities and a random asymmetric star, against the CPU
+    oracle."""
     rng = np.random.default_rng(seed)
     v = rng.uniform(0.1, 0.5, size=shape).astype(np.float32)
     offs = rng.integers(-7, 8, size=(60, 3)).astype(np.int32)

@@ -173,9 +173,6 @@ static void make_layout_strip(ttsweep_ctx *ctx)
         if (d != bax) rest[k++] = d;
     int cax = rest[1], aax = rest[0];       // ties: keep the user's fastest axis as c
     if (util(n[rest[0]], STRIP_K) > util(n[rest[1]], STRIP_K) + 1e-12) { cax = rest[0]; aax = rest[1]; }
-    if (const char *env = getenv("TTSWEEP_AXES")) {       // experiments: "abc" as digits, e.g. 210
-        if (strlen(env) == 3) { aax = env[0] - '0'; bax = env[1] - '0'; cax = env[2] - '0'; }
-    }
     L.perm[0] = aax;
     L.perm[1] = bax;
     L.perm[2] = cax;
