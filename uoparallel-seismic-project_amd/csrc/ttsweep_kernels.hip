@@ -314,8 +314,9 @@ hipError_t launch_validate(const DevLayout &L, const float *v, const float *T, l
 
 // The first words of the dynamic LDS region carry workgroup-wide scalars (no static
 // __shared__ object: it would shift the 16-byte alignment of the dynamic base).
-constexpr int STRIP_LDS_HEAD = 16 + 64;     // words reserved in front of the slabs: 16 scalars, then
-                                            // the waves' column ranges per plane offset (sweep_units_kernel)
+constexpr int STRIP_LDS_HEAD = 16 + 64 + 16;     // words reserved in front of the slabs: 16 scalars, the
+                                            // waves' column ranges per plane offset, the offsets per
+                                            // plane offset (sweep_units_kernel)
 // slab geometry (bytes): up to 64 + 2*7 rows, rounded up to 8, of 128 B for v, then for T
 constexpr int SLAB_MAX_ROWS8 = (STRIP_TB + 2 * STRIP_MAX_RA + 7) / 8 * 8;
 constexpr int SLAB_T_BYTES = SLAB_MAX_ROWS8 * STRIP_W * 4;
@@ -806,6 +807,8 @@ sweep_units_kernel(DevLayout L, const float *__restrict__ v, const StartDesc *__
             packed = (plan.first[ia] + plan.wsplit[ia][w]) | ((plan.first[ia] + plan.wsplit[ia][w + 1]) << 16);
         col_range[tid] = packed;
     }
+    int *plane_nent = col_range + NS * 16;          // offsets per plane offset (statistics)
+    if (tid < 16) plane_nent[tid] = tid <= 2 * plan.ra ? plan.nent[tid] : 0;
     __syncthreads();
 
     // ---- the dead-edge cells of the active starts, one wave per cell
@@ -853,8 +856,9 @@ sweep_units_kernel(DevLayout L, const float *__restrict__ v, const StartDesc *__
         if (tid == 0) {     // statistics: cells x offsets relaxed, units
             const int wb = min(tb_eff, L.n[1] - b0), wc = max(min(K, L.n[2] - c0), 0);
             int nent = 0;
-            for (int ia = 0; ia <= 2 * plan.ra; ia++)
-                if ((my_planes >> ia) & 1u) nent += plan.nent[ia];
+#pragma unroll
+            for (int ia = 0; ia < 16; ia++)
+                if ((my_planes >> ia) & 1u) nent += plane_nent[ia];
             atomicAdd(sd.work, (unsigned long long)(wb * wc) * (unsigned long long)nent);
             atomicAdd(sd.work + 2, 1ull);
         }
