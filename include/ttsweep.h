@@ -52,9 +52,10 @@ typedef struct ttsweep_start {
 /* Counters of the most recent solve on a context. */
 typedef struct ttsweep_stats {
     int nstart;                 /* starts in the solve */
-    int sweeps_max;             /* full-grid passes executed for the slowest start */
-    long long sweeps_total;     /* sum over starts of passes launched (a pass may skip
-                                   tiles whose inputs did not change) */
+    int sweeps_max;             /* passes executed for the slowest start */
+    long long sweeps_total;     /* sum over starts of passes launched (a pass relaxes only
+                                   the units that are due: whose inputs changed and that the
+                                   distance gate has reached) */
     long long cells_relaxed;    /* cells actually relaxed against the whole star, summed
                                    over passes and starts (= sweeps_total * cells when
                                    nothing is skipped) */

@@ -92,7 +92,7 @@ struct ttsweep_ctx {
     int unitq_blocks = 0;                   // persistent grid: workgroups the device holds at once
     std::vector<std::vector<int>> unit_order;       // per start: unit ids, nearest to the start first
     std::vector<long long> unit_order_key;          // start cell the cached order belongs to
-    // Distance gate (see sweep_strip_kernel): radius of the first pass and cells it opens per
+    // Distance gate (see plan_pass_kernel): radius of the first pass and cells it opens per
     // pass.  Defaults follow the star's reach: final values spread at about half the reach
     // per pass (measured, 818-offset star: 3.5 cells/pass gives the shortest solve).
     double gate_speed = 0.0;                // 0: no gate
@@ -345,7 +345,7 @@ static int upload_star(ttsweep_ctx *ctx)
 }
 
 // Activity words of one start: two parities of unit flags, the held-back plane bits and the
-// number of source units (see sweep_strip_kernel).
+// number of source units (see plan_pass_kernel).
 static size_t flag_words(const DevLayout &L) { return 3 * (size_t)std::max(strip_units(L), 1) + 4; }
 
 static int ensure_capacity(ttsweep_ctx *ctx, int nstart)
@@ -393,14 +393,15 @@ static int timed_event(ttsweep_ctx *ctx, hipEvent_t *out)
     return 0;
 }
 
-// STRIP work list.  The hardware deals consecutive blocks round-robin over the 8
-// XCDs (observed behaviour, used for speed only), so block b runs on XCD b % 8.
-// Every active start is given a set of XCDs (one XCD when there are >= 8 starts,
-// several when there are fewer) and its tiles are queued on those XCDs nearest to
-// the start point first.  Tiles of one start therefore mostly share one L2, and a
-// tile usually runs after the tiles between it and the start have finished their
-// update of this pass: fresh travel times then cross several tiles in ONE pass
-// instead of one tile per pass.  Correctness never depends on this order.
+// STRIP work list (static order of the units, input of plan_pass_kernel).  The hardware
+// deals consecutive workgroups round-robin over the 8 XCDs (observed behaviour, used for
+// speed only), and entry i of the list belongs to queue i % 8.  Every active start is
+// given a set of XCDs (one XCD when there are >= 8 starts, several when there are fewer)
+// and its units are listed for those XCDs nearest to the start point first.  The units of
+// one start therefore mostly share one L2, and a unit usually runs after the units between
+// it and the start have finished their update of this pass: fresh travel times then cross
+// several units in ONE pass instead of one unit per pass.  Correctness never depends on
+// this order.
 static int build_worklist(ttsweep_ctx *ctx, int nactive)
 {
     const auto t_begin = std::chrono::steady_clock::now();

@@ -61,8 +61,9 @@ struct StartDesc {
     // that have at least one dead edge: the STRIP kernel does not store into
     // them, the exact wave-per-cell kernel owns them.  Empty if lo > hi.
     int box_lo[3], box_hi[3];
-    // STRIP kernel activity tracking: tile_flags[parity][tile] != 0 iff some cell of
-    // that tile improved in the pass with that parity (see sweep_strip_kernel).
+    // STRIP activity tracking, per unit (see plan_pass_kernel): tile_flags[parity][unit]
+    // says where the unit improved in the pass with that parity; then one word per unit
+    // of held-back plane bits (pend[]), then the number of source units.
     int *tile_flags;
     unsigned long long *work;   // cells actually relaxed for this start (sum over passes)
 };
