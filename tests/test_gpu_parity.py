@@ -361,6 +361,37 @@ def test_volume_above_2_gib(P):
         assert torch.equal(before.view(torch.int32), tt.view(torch.int32))
 
 
+@pytest.mark.parametrize("sname,key,nslice", [("818", "818_mid", 3), ("5", "5_corner", 2),
+                                             ("818", "818_deadin", 8)])
+def test_star_split_single_start(P, golden24, sname, key, nslice):
+    """One start, the star split over `nslice` contexts (the single-start multi-GPU
+    scheme; the "ranks" are played in one process here): each context
+    relaxes only offsets [lo, hi), rounds are min-combined, and the result is the fixture
+    of the whole star, bit for bit."""
+    import torch
+    dev = torch.device("cuda:0")
+    offs = golden24.star(sname)
+    fs = P.inputs.make_fs(offs)
+    start = golden24.z[f"start_{key}"]
+    shape = golden24.v.shape
+    sols, fns = [], []
+    try:
+        for lo, hi in P.multistart.star_slices(len(fs) - 1, nslice):
+            sol = P.TravelTimeSolver(shape, fs, starstart=lo, starstop=hi)
+            sol.set_velocity(golden24.v)
+            sols.append(sol)
+            fns.append(lambda box, sol=sol: sol.solve_device([start], box[None], init=False) == 1)
+        tt = np.full(shape, np.inf, dtype=np.float32)
+        tt[tuple(start)] = 0
+        box = torch.from_numpy(tt).to(dev)
+        rounds = P.multistart.solve_star_split_local(box, fns)
+    finally:
+        for sol in sols:
+            sol.close()
+    assert rounds >= 2
+    assert_bit_equal(box.cpu().numpy(), golden24.z[f"tt_{key}"], key)
+
+
 def test_solve_multi_shards_starts_over_devices(P, golden24):
     """ttsweep_solve_multi with two device slots (both GPU 0 on a one-GPU box: two
     contexts, two host threads): every start ends bit-equal to its fixture."""

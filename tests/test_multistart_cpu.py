@@ -75,3 +75,62 @@ def test_shard_assignment_is_a_partition(pkg):
             assert flat == list(range(nstart))
             assert pkg.multistart.shard_sizes(nstart, world) == [len(sh) for sh in shards]
             assert max(map(len, shards)) - min(map(len, shards)) <= 1
+
+
+# --------------------------------------------------------------------------
+# one start on several ranks: star split + all-reduce(min)
+# --------------------------------------------------------------------------
+
+def split_worker(rank, world, port, star, outdir):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import oracle as O
+    import ttsweep_pkg
+    P = ttsweep_pkg.load()
+    shape = (12, 10, 7)
+    v = P.inputs.velocity_model(*shape, seed=33)
+    fs = O.make_star(P.inputs.read_triples(P.inputs.star_path(star)))
+    start = (3, 8, 6)
+    lo, hi = P.multistart.star_slices(len(fs) - 1, world)[rank]
+
+    def slice_solve(box):
+        tt = box.numpy()                                    # shares memory: relaxed in place
+        if hi <= lo:
+            return False
+        _, _, stores = O.converge(v, fs, start, starstart=lo, starstop=hi, tt=tt)
+        return stores > 0
+
+    box = torch.from_numpy(O.tt_init(shape, start))
+    rounds = P.multistart.solve_star_split(box, slice_solve, dist)
+    np.save(os.path.join(outdir, f"split_{rank}.npy"), box.numpy())
+    if rank == 0:
+        np.save(os.path.join(outdir, "rounds.npy"), np.array([rounds]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,star", [(2, "3"), (3, "5")])
+def test_star_split_reaches_the_full_star_fixed_point(tmp_path, oracle, pkg, world, star):
+    """Every rank relaxes only its slice of the offsets; with an all-reduce(min) per round
+    all ranks end with the box the whole star converges to, bit for bit."""
+    port = free_port()
+    mp.spawn(split_worker, args=(world, port, star, str(tmp_path)), nprocs=world, join=True)
+    shape = (12, 10, 7)
+    v = pkg.inputs.velocity_model(*shape, seed=33)
+    fs = oracle.make_star(pkg.inputs.read_triples(pkg.inputs.star_path(star)))
+    want, _, _ = oracle.converge(v, fs, (3, 8, 6))
+    for r in range(world):
+        got = np.load(tmp_path / f"split_{r}.npy")
+        assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), r
+    assert int(np.load(tmp_path / "rounds.npy")[0]) >= 2
+
+
+def test_star_slices_partition_the_offsets(pkg):
+    for n, k in [(817, 8), (97, 3), (5, 8), (0, 2), (1, 1)]:
+        sl = pkg.multistart.star_slices(n, k)
+        assert len(sl) == k and sl[0][0] == 0 and sl[-1][1] == n
+        assert all(a[1] == b[0] for a, b in zip(sl, sl[1:]))
+        assert max(h - l for l, h in sl) - min(h - l for l, h in sl) <= 1

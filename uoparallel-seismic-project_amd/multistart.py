@@ -68,3 +68,82 @@ def solve_sharded(starts: Sequence, solve_fn: Callable, dist=None, dst: int = 0)
     mine = shard_starts(len(starts), world, rank)
     local = solve_fn(starts[mine])
     return gather_boxes(local, len(starts), dist, dst), local
+
+
+# --------------------------------------------------------------------------
+# one start on several GPUs: star split + all-reduce(min)
+# --------------------------------------------------------------------------
+
+def star_slices(noffsets: int, nslice: int):
+    """Contiguous, nearly equal slices [lo, hi) of the offsets l in [0, noffsets) - the
+    range sweepXYZ walks, serial_new/sweep-tt-multistart.c:160,206 (noffsets =
+    starsize - 1: the last star entry is never an offset).  Empty slices are kept so
+    that every rank has one."""
+    base, extra = divmod(max(noffsets, 0), nslice)
+    out, lo = [], 0
+    for r in range(nslice):
+        hi = lo + base + (1 if r < extra else 0)
+        out.append((lo, hi))
+        lo = hi
+    return out
+
+
+def solve_star_split(box, slice_solve_fn: Callable, dist=None, max_rounds: int = 100000):
+    """One start point on all ranks (precedent: cuda/cudasweep-tt-multistart.cu:316-384, the
+    reference's star split with a per-sweep reduction).  Every rank holds the same box
+    `box` (torch tensor [nx,ny,nz]: INFINITY, start 0 - or any later state) and relaxes
+    only ITS slice of the star: `slice_solve_fn(box) -> bool` brings the box, in place, to
+    the fixed point of the rank's offsets and says whether anything changed.  After each
+    round the boxes are combined with an element-wise all-reduce(min) (RCCL over xGMI for
+    backend "nccl"); the loop ends after a round in which no rank changed anything - the
+    box is then a fixed point of every slice, i.e. of the whole star, and since the slices'
+    edge sets add up to the reference's edge set it is bit-identical to the single-GPU
+    result.  Returns the number of rounds.
+
+    min is associative, commutative and idempotent, so the order of the reduction does not
+    matter.  This is a correctness path for runs with fewer starts than GPUs, not a fast
+    one: shortest paths alternate between offsets of different slices at almost every hop,
+    so it needs about as many rounds (each with a reduction of the whole box) as the
+    single-GPU solve needs passes."""
+    import torch
+
+    multi = dist is not None and dist.is_initialized() and dist.get_world_size() > 1
+    rounds = 0
+    while True:
+        rounds += 1
+        if rounds > max_rounds:
+            raise RuntimeError("solve_star_split: no convergence")
+        changed = bool(slice_solve_fn(box))
+        if not multi:
+            if not changed:
+                return rounds
+            continue
+        flag = torch.tensor([1 if changed else 0], dtype=torch.int32, device=box.device)
+        dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+        if int(flag.item()) == 0:
+            return rounds
+        dist.all_reduce(box, op=dist.ReduceOp.MIN)
+
+
+def solve_star_split_local(box, slice_solve_fns: Sequence[Callable], max_rounds: int = 100000):
+    """The same iteration with the "ranks" played one after the other in this process
+    (tests, and hosts that drive several contexts themselves): every round each slice
+    solver starts from the round's common box, then the results are min-combined."""
+    import torch
+
+    rounds = 0
+    while True:
+        rounds += 1
+        if rounds > max_rounds:
+            raise RuntimeError("solve_star_split_local: no convergence")
+        results, any_changed = [], False
+        for fn in slice_solve_fns:
+            mine = box.clone()
+            any_changed |= bool(fn(mine))
+            results.append(mine)
+        if not any_changed:
+            return rounds
+        combined = results[0]
+        for r in results[1:]:
+            combined = torch.minimum(combined, r)
+        box.copy_(combined)
