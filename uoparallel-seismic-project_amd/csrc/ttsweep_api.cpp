@@ -417,7 +417,8 @@ static int build_worklist(ttsweep_ctx *ctx, int nactive)
                     per_xcd[x].push_back(make_int2(s, ctx->unit_order[s][k]));
                 }
     } else {
-        // start a owns XCDs a, a+nactive, ...; deal its units over them
+        // start a owns XCDs a, a+nactive, ...; deal its units over them (dealing whole
+        // sectors around the start to one XCD each was measured: no less work, worse balance)
         for (int a = 0; a < nactive; a++) {
             const int s = ctx->h_active[a];
             std::vector<int> mine;
@@ -461,7 +462,11 @@ static int build_worklist(ttsweep_ctx *ctx, int nactive)
     return 0;
 }
 
-// Units of one start ordered by distance (unit centre to start point).
+// Units of one start ordered by distance (unit centre to start point).  The queues hand
+// the units out in this order, so a unit usually starts after the units between it and the
+// start have finished their update of this pass and sees their fresh values (measured:
+// 8 % less work and 6 % less time than an order that keeps runs of neighbouring planes
+// together for cache locality).
 static void order_units(const ttsweep_ctx *ctx, const StartDesc &sd, std::vector<int> &order)
 {
     const DevLayout &L = ctx->L;
@@ -472,13 +477,8 @@ static void order_units(const ttsweep_ctx *ctx, const StartDesc &sd, std::vector
         const int cs = t % cstrips, bt = (t / cstrips) % btiles, a = t / (cstrips * btiles);
         const long long cb = std::min(bt * STRIP_TB + STRIP_TB / 2, L.n[1] - 1);
         const long long cc = std::min(cs * STRIP_K + STRIP_K / 2, L.n[2] - 1);
-        const long long db = cb - sd.sb, dc = cc - sd.sc;
-        // runs of RUN consecutive planes (the planes a unit stages are then mostly L2 hits
-        // left by its predecessor), runs ordered by distance from the start
-        constexpr int RUN = 8;
-        const long long ca = (a / RUN) * RUN + RUN / 2;
-        const long long dq = ca - sd.sa;
-        key[t] = {(dq * dq + db * db + dc * dc) * 64 + a % RUN, t};
+        const long long da = a - sd.sa, db = cb - sd.sb, dc = cc - sd.sc;
+        key[t] = {da * da + db * db + dc * dc, t};
     }
     std::sort(key.begin(), key.end());
     order.resize(nunits);
