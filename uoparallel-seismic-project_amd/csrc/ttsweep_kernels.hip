@@ -726,20 +726,24 @@ __device__ __forceinline__ void stage_slab(const float *__restrict__ v_slab, con
     const buf_rsrc rv = make_rsrc(v_slab), rt = make_rsrc(t_slab);
     const int ninstr = rows8 / 8;           // wave-instructions per array
     const int rloc = lane >> 3, p = lane & 7;
-    // row r = 8 kk + rloc has swizzle ((r >> 1) & 7) = (rloc >> 1) ^ (4 (kk & 1))
+    // Wave w loads the 8-row groups kk = w, w + 4, ... of both arrays.  Row r = 8 kk + rloc
+    // has swizzle ((r >> 1) & 7) = (rloc >> 1) ^ (4 (kk & 1)), and kk & 1 = w & 1 for all of
+    // a wave's groups, so one per-lane byte offset serves all its loads (but the slab's last
+    // group, whose rows past the slab re-read its last row).
     const unsigned lane_row = (unsigned)rloc * s1_bytes;
-    const unsigned voff_even = lane_row + (unsigned)((p ^ (rloc >> 1)) << 4);
-    const unsigned voff_odd = lane_row + (unsigned)((p ^ (rloc >> 1) ^ 4) << 4);
-    for (int k = wave; k < 2 * ninstr; k += STRIP_NS) {
-        const bool is_t = k >= ninstr;
-        const int kk = is_t ? k - ninstr : k;
-        unsigned voff = (kk & 1) ? voff_odd : voff_even;
-        if (kk == ninstr - 1)               // rows past the slab re-read its last row
-            voff -= (unsigned)max(kk * 8 + rloc - (rows - 1), 0) * s1_bytes;
-        const unsigned soff = (unsigned)(kk * 8) * s1_bytes;
-        float *dst = slab + (is_t ? SLAB_T_BYTES / 4 : 0) + kk * (8 * STRIP_W);     // wave-uniform
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(is_t ? rt : rv, (__attribute__((address_space(3))) void *)dst,
-                                                 16, (int)voff, (int)soff, 0, 0);
+    const unsigned voff = lane_row + (unsigned)((p ^ (rloc >> 1) ^ ((wave & 1) << 2)) << 4);
+    const unsigned voff_last = voff - (unsigned)max((ninstr - 1) * 8 + rloc - (rows - 1), 0) * s1_bytes;
+    const unsigned group_bytes = 8 * s1_bytes;
+    unsigned soff = (unsigned)wave * group_bytes;
+    float *dst = slab + wave * (8 * STRIP_W);                               // wave-uniform
+    for (int kk = wave; kk < ninstr; kk += STRIP_NS) {
+        const int vo = (int)(kk == ninstr - 1 ? voff_last : voff);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rv, (__attribute__((address_space(3))) void *)dst,
+                                                 16, vo, (int)soff, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rt, (__attribute__((address_space(3))) void *)(dst + SLAB_T_BYTES / 4),
+                                                 16, vo, (int)soff, 0, 0);
+        soff += STRIP_NS * group_bytes;
+        dst += STRIP_NS * 8 * STRIP_W;
     }
 }
 
