@@ -453,7 +453,9 @@ static int build_worklist(ttsweep_ctx *ctx, int nactive)
     if (ctx->unitq_blocks == 0) {
         hipDeviceProp_t prop;
         HIPCHK(hipGetDeviceProperties(&prop, ctx->device));
-        const int wgs = 3 * std::max(prop.multiProcessorCount, 1);     // 3 workgroups (12 waves) per CU
+        const int wgs = 2 * std::max(prop.multiProcessorCount, 1);     // 2 workgroups (8 waves) per CU:
+            // measured optimum - a third one adds no throughput, lengthens every unit and lets
+            // fewer units see their neighbours' updates of the same pass
         ctx->unitq_blocks = ((wgs + UNITQ_LISTS - 1) / UNITQ_LISTS) * UNITQ_LISTS;
     }
     if (getenv("TTSWEEP_TRACE"))

@@ -572,7 +572,7 @@ hipError_t launch_init_tile_flags(const DevLayout &L, const StartDesc &sd, bool 
 // Only a shell of units is due in any pass, and most workgroups of a grid-per-unit launch
 // would start, read their neighbours' flags and leave.  A pass therefore runs in two steps: plan_pass_kernel (one THREAD per unit) decides which units
 // are due and writes them, in work-list order, into one queue per XCD; sweep_units_kernel,
-// a grid of as many workgroups as the chip holds at once, drains the queues (own XCD's
+// a grid of two workgroups per CU, drains the queues (own XCD's
 // first, then the others').  A workgroup relaxes ONE unit at a time, its four waves
 // splitting the star's columns among themselves (nearly equal shares, StripPlan::wsplit)
 // and min-combining their partial results through LDS.
@@ -774,7 +774,7 @@ void prof_dump()
 #endif
 
 template <int K>
-__global__ void __launch_bounds__(STRIP_TB *STRIP_NS, 3)
+__global__ void __launch_bounds__(STRIP_TB *STRIP_NS, 2)
 sweep_units_kernel(DevLayout L, const float *__restrict__ v, const StartDesc *__restrict__ starts,
                    const int4 *__restrict__ lists, int list_cap, int *__restrict__ ctrl,
                    int *__restrict__ changed, const StripCol *__restrict__ cols, StripPlan plan,
