@@ -392,6 +392,22 @@ def test_star_split_single_start(P, golden24, sname, key, nslice):
     assert_bit_equal(box.cpu().numpy(), golden24.z[f"tt_{key}"], key)
 
 
+@pytest.mark.parametrize("speed,r0", [("0", "0"), ("0.5", "1"), ("2", "3"), ("9", "30")])
+def test_result_does_not_depend_on_the_gate(P, golden24, monkeypatch, speed, r0):
+    """The distance gate only decides WHEN a unit is relaxed: switched off, crawling or far
+    ahead of the front, the converged boxes are the same bits (818-FS, interior, corner and
+    dead-edge starts in one batch)."""
+    monkeypatch.setenv("TTSWEEP_GATE_SPEED", speed)
+    monkeypatch.setenv("TTSWEEP_GATE_R0", r0)
+    fs = P.inputs.make_fs(golden24.star("818"))
+    keys = ["818_mid", "818_corner", "818_deadin", "818_deadout"]
+    starts = np.array([golden24.z[f"start_{k}"] for k in keys], dtype=np.int32)
+    tts, rc, st = gpu_converge(P, golden24.v, fs, starts)
+    assert rc == 1 and st["kernel_variant"] == 2
+    for k, tt in zip(keys, tts):
+        assert_bit_equal(tt, golden24.z[f"tt_{k}"], f"{k} gate {speed}/{r0}")
+
+
 def test_solve_multi_shards_starts_over_devices(P, golden24):
     """ttsweep_solve_multi with two device slots (both GPU 0 on a one-GPU box: two
     contexts, two host threads): every start ends bit-equal to its fixture."""
