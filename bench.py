@@ -59,6 +59,34 @@ def cpu_baseline(P, v, offs, start, sweeps=4):
                       f"(single thread, gcc -O3; host has {os.cpu_count()} logical cores)"}
 
 
+def cpu_baseline_cores(shape, star, starts_name, ncores, sweeps=1):
+    """The same CPU restatement with one start per core (the strategy of the reference's
+    mpi/backup.c:351-363), `ncores` processes side by side, each `sweeps` reference-order
+    passes of its own start.  Child processes: they never touch the GPU."""
+    import subprocess
+    script = os.path.join(ROOT, "oracle", "cpu_sample.py")
+    args = [str(n) for n in shape] + [star, starts_name]
+    t0 = time.perf_counter()
+    procs = [subprocess.Popen([sys.executable, script] + args + [str(i), str(sweeps)],
+                              stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True)
+             for i in range(ncores)]
+    secs = []
+    for p in procs:
+        out, _ = p.communicate()
+        if p.returncode == 0:
+            secs.append(float(out.strip().splitlines()[-1]))
+    wall = time.perf_counter() - t0
+    if len(secs) != ncores:
+        return None
+    cells = shape[0] * shape[1] * shape[2]
+    # rate while all cores sweep together: each finished `sweeps` passes in its own time
+    return {"value": sum(cells * sweeps / t for t in secs) / 1e6, "unit": "Mcells*sweeps/s",
+            "cores": ncores, "kind": "port", "seconds": round(max(secs), 2),
+            "wall_seconds_incl_startup": round(wall, 2),
+            "sample": f"{sweeps} reference-order pass(es) of {ncores} different starts, one process per "
+                      f"core, side by side (host has {os.cpu_count()} logical cores)"}
+
+
 def measured_traffic():
     """HBM-side bytes per sweep-kernel launch from the rocprofv3 PMC passes of this same
     command (FETCH_SIZE and WRITE_SIZE in separate runs, gfx950 x2 read correction),
@@ -216,6 +244,11 @@ def main():
         }
         if world == 1 and not args.no_cpu and v_host is not None:
             out["cpu_baseline"] = cpu_baseline(P, v_host, offs, starts[0])
+            ncores = min(16, os.cpu_count() or 1)
+            if ncores > 1:
+                multi = cpu_baseline_cores((nx, ny, nz), args.star, args.starts, ncores)
+                if multi is not None:
+                    out["cpu_baseline_all_cores"] = multi
         print(json.dumps(out), flush=True)
     sol.close()
     if dist is not None:
