@@ -148,6 +148,35 @@ def test_seeded_random_vs_oracle(P, oracle, shape, seed, kernel):
     assert_bit_equal(tt, want, str(shape))
 
 
+def test_fuzz_shapes_stars_starts_vs_oracle(P, oracle):
+    """Ten seeded random cases - grid shape (1..140 per axis), star (818-FS, 5-FS, random
+    asymmetric stars of radius <= 7 or <= 3), 1-3 starts per solve - against the CPU oracle."""
+    rng = np.random.default_rng(2026)
+    for case in range(10):
+        shape = tuple(int(x) for x in rng.integers(1, 90, size=3))
+        if rng.random() < 0.3:
+            shape = tuple(int(x) for x in rng.integers(60, 140, size=3))
+        if np.prod(shape) > 250000:
+            shape = (shape[0] // 2 + 1, shape[1], shape[2] // 2 + 1)
+        v = rng.uniform(0.05, 0.6, size=shape).astype(np.float32)
+        kind = int(rng.integers(0, 4))
+        if kind == 0:
+            offs = P.inputs.read_triples(P.inputs.star_path("818"))
+        elif kind == 1:
+            offs = P.inputs.read_triples(P.inputs.star_path("5"))
+        else:
+            r = 7 if kind == 2 else 3
+            offs = rng.integers(-r, r + 1, size=(int(rng.integers(3, 80)), 3)).astype(np.int32)
+            offs = offs[np.any(offs != 0, axis=1)]
+        nstart = int(rng.integers(1, 4))
+        starts = np.stack([rng.integers(0, n, size=nstart) for n in shape], axis=1).astype(np.int32)
+        tts, _, st = gpu_converge(P, v, P.inputs.make_fs(offs), starts)
+        ofs = oracle.make_star(offs)
+        for start, tt in zip(starts, tts):
+            want, _, _ = oracle.converge(v, ofs, start, order=1)
+            assert_bit_equal(tt, want, f"case {case} {shape} star kind {kind} start {tuple(start)}")
+
+
 def test_large_radius_star_falls_back_to_cell_kernel(P, oracle):
     """Offsets beyond +-7 (FSRADIUSMAX, serial_new/...:41) are outside the STRIP
     kernel's window; the library must still solve them (CELL kernel)."""
