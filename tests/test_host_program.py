@@ -70,3 +70,30 @@ def test_host_program_rejects_bad_input(exe, tmp_path):
     (tmp_path / "junk.vbox").write_bytes(b"not a vbox file at all")
     r = subprocess.run([exe, "junk.vbox", "x", "y"], cwd=tmp_path, capture_output=True, text=True)
     assert r.returncode == 1 and "Cannot open velocity model file" in r.stdout
+
+
+def test_bench_prints_one_contract_line(pkg):
+    """bench.py (the driver's entry point): exactly one JSON line on stdout with the keys of
+    the contract, the roofline and (with --no-cpu) no CPU leg; value = cells relaxed / time."""
+    import json
+    import sys
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "1", "--warmup", "0",
+                        "--nstarts", "2", "--no-cpu"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better",
+                "scaling", "vs_baseline", "dtype", "data", "config", "roofline"):
+        assert key in d, key
+    assert d["n_gpus"] == 1 and d["steps"] == 1 and d["warmup"] == 0 and d["vs_baseline"] is None
+    assert d["unit"] == "Mcells*sweeps/s" and d["dtype"] == "f32" and d["data"] == "synthetic"
+    assert "workload" in d["config"] and "model" not in d["config"] and d["config"]["starts"] == 2
+    rf = d["roofline"]
+    for key in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert key in rf, key
+    assert rf["bound"] == "hbm" and rf["peak"] == 8000.0 and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-12
+    assert d["value"] > 0 and d["ms_per_step"] > 0 and "cpu_baseline" not in d
+    cells = 241 * 241 * 51
+    eq = d["config"]["full_sweep_equivalents_per_start_mean"]
+    assert abs(d["value"] - eq * 2 * cells / (d["ms_per_step"] / 1e3) / 1e6) < 1e-6 * d["value"]
