@@ -146,7 +146,7 @@ def big_digests():
         json.dump(res, open(path, "w"), indent=1)
 
 
-def big_start24(idx, which="24"):
+def big_start24(idx, which="24", star="818"):
     """One start of a BASELINE start file (start-24 by default, --big-file 4 for start-4) on
     the 241x241x51 model, 818-FS, through the reference; written to its own file so several
     can run in parallel (merge_big)."""
@@ -154,12 +154,12 @@ def big_start24(idx, which="24"):
     starts = O.read_triples(os.path.join(ROOT, "data", "starts", f"start-{which}-241-241-51.txt"))
     st = starts[idx]
     t0 = time.time()
-    (tt,), sweeps = O.ref_converge(v, shipped("818"), [st.astype(np.int32)])
-    res = {f"syn241_818_{st[0]}_{st[1]}_{st[2]}": {
+    (tt,), sweeps = O.ref_converge(v, shipped(star), [st.astype(np.int32)])
+    res = {f"syn241_{star}_{st[0]}_{st[1]}_{st[2]}": {
         "sha256": hashlib.sha256(tt.tobytes()).hexdigest(), "sweeps": int(sweeps),
         "seconds": round(time.time() - t0, 1), "spots": {}, f"start{which}_index": int(idx),
         "max": float(tt.max()), "mean": float(tt.astype(np.float64).mean())}}
-    json.dump(res, open(os.path.join(HERE, f"big_part_{which}_{idx}.json"), "w"), indent=1)
+    json.dump(res, open(os.path.join(HERE, f"big_part_{star}_{which}_{idx}.json"), "w"), indent=1)
     print(res, flush=True)
 
 
@@ -179,10 +179,11 @@ if __name__ == "__main__":
     ap.add_argument("--big", action="store_true")
     ap.add_argument("--big-start", type=int, default=None)
     ap.add_argument("--big-file", default="24")
+    ap.add_argument("--big-star", default="818")
     ap.add_argument("--merge-big", action="store_true")
     args = ap.parse_args()
     if args.big_start is not None:
-        big_start24(args.big_start, args.big_file)
+        big_start24(args.big_start, args.big_file, args.big_star)
         sys.exit(0)
     if args.merge_big:
         merge_big()
