@@ -29,8 +29,7 @@ def pkg():
     """The product package with libttsweep.so built (hipcc cross-compiles on CPU)."""
     import ttsweep_pkg
     P = ttsweep_pkg.load()
-    if not os.path.exists(P._lib.LIB_PATH):
-        P._lib.build()
+    P._lib.build()          # `make` is incremental: a stale .so is never tested against new sources
     return P
 
 

@@ -365,6 +365,45 @@ def test_512_grid_properties(P):
     assert sampled_open_edges(v, tt, offs, starts[0], 20000, 2) == 0
 
 
+def _batched_config_check(P, shape, nstart, star="818"):
+    """One batched device-resident solve of `nstart` scaled start-111 points on a synthetic
+    grid; every box is then pinned by the device validator (nothing can improve, nothing is
+    too small, nothing left at INFINITY), and a second solve of the converged boxes must
+    report "no change" and leave every bit alone."""
+    import torch
+    dev = torch.device("cuda:0")
+    v_dev = P.inputs.velocity_model_device(*shape, 20160507, dev)
+    fs = P.inputs.make_fs(P.inputs.read_triples(P.inputs.star_path(star)))
+    starts = P.inputs.scaled_starts(P.inputs.read_triples(P.inputs.starts_path("111")), *shape)[:nstart]
+    assert len(starts) == nstart
+    with P.TravelTimeSolver(shape, fs) as sol:
+        sol.set_velocity(v_dev)
+        tt = torch.empty((nstart,) + shape, dtype=torch.float32, device=dev)
+        assert sol.solve_device(starts, tt, init=True) == 1
+        st = sol.stats()
+        assert st["nstart"] == nstart
+        for s in range(nstart):
+            assert sol.validate_device(starts[s], tt[s]) == (0, 0, 0), f"start {s} {starts[s]}"
+            assert float(tt[s][tuple(starts[s])]) == 0.0
+        assert bool(torch.isfinite(tt).all()) and float(tt.min()) == 0.0
+        digest = [int(tt[s].view(torch.int32).to(torch.int64).sum().item()) for s in range(nstart)]
+        assert sol.solve_device(starts, tt, init=False) == 0
+        assert digest == [int(tt[s].view(torch.int32).to(torch.int64).sum().item()) for s in range(nstart)]
+        return st
+
+
+def test_config_512_grid_eight_starts(P):
+    """BASELINE.json config 4 at its stated batch: 512x512x256, 8 starts, 818-FS, one
+    batched solve (8 travel-time volumes resident, work list of 8 x the unit grid)."""
+    _batched_config_check(P, (512, 512, 256), 8)
+
+
+def test_config_1024_grid_one_gpu_share(P):
+    """BASELINE.json config 5, one GPU's share of the 111 starts (ceil(111 / 8) = 14) on
+    1024x1024x512 with the 818-FS star: 14 padded volumes of 2.3 GB in one batch."""
+    _batched_config_check(P, (1024, 1024, 512), 14)
+
+
 def test_volume_above_2_gib(P):
     """818-FS on 1024x1024x512 (padded volumes of 2.3 GB: byte offsets beyond 2^31 inside one
     volume).  No second implementation is fast enough here, so the box is pinned by the
