@@ -76,6 +76,12 @@ typedef struct ttsweep_ctx ttsweep_ctx;
 #define TTSWEEP_OPT_MAX_SWEEPS    3   /* safety cap on passes per solve (default 100000) */
 #define TTSWEEP_OPT_MAX_BATCH     4   /* ttsweep_solve: at most this many starts per device
                                          batch (0 = as many as device memory holds) */
+#define TTSWEEP_OPT_GATE_SPEED_MILLI 5 /* schedule only, never the result: cells (x 1/1000) by
+                                          which the distance gate of the STRIP kernel opens per
+                                          pass; 0 switches the gate off (default: half the
+                                          star's reach) */
+#define TTSWEEP_OPT_GATE_R0_MILLI 6   /* schedule only: gate radius of the first pass, cells x 1/1000
+                                         (default: the star's reach + 1) */
 
 #define TTSWEEP_KERNEL_AUTO       0
 #define TTSWEEP_KERNEL_CELL       1   /* one thread per cell, star from global memory */

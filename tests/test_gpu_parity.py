@@ -460,20 +460,60 @@ def test_star_split_single_start(P, golden24, sname, key, nslice):
     assert_bit_equal(box.cpu().numpy(), golden24.z[f"tt_{key}"], key)
 
 
-@pytest.mark.parametrize("speed,r0", [("0", "0"), ("0.5", "1"), ("2", "3"), ("9", "30")])
-def test_result_does_not_depend_on_the_gate(P, golden24, monkeypatch, speed, r0):
+@pytest.mark.parametrize("speed,r0", [(0, 0), (500, 1000), (2000, 3000), (9000, 30000)])
+def test_result_does_not_depend_on_the_gate(P, golden24, speed, r0):
     """The distance gate only decides WHEN a unit is relaxed: switched off, crawling or far
     ahead of the front, the converged boxes are the same bits (818-FS, interior, corner and
     dead-edge starts in one batch)."""
-    monkeypatch.setenv("TTSWEEP_GATE_SPEED", speed)
-    monkeypatch.setenv("TTSWEEP_GATE_R0", r0)
     fs = P.inputs.make_fs(golden24.star("818"))
     keys = ["818_mid", "818_corner", "818_deadin", "818_deadout"]
     starts = np.array([golden24.z[f"start_{k}"] for k in keys], dtype=np.int32)
-    tts, rc, st = gpu_converge(P, golden24.v, fs, starts)
-    assert rc == 1 and st["kernel_variant"] == 2
+    tts = []
+    for st in starts:
+        tt = np.full(golden24.v.shape, np.inf, dtype=np.float32)
+        tt[tuple(st)] = 0
+        tts.append(tt)
+    with P.TravelTimeSolver(golden24.v.shape, fs) as sol:
+        sol.set_option(P.OPT_GATE_SPEED_MILLI, speed)
+        sol.set_option(P.OPT_GATE_R0_MILLI, r0)
+        sol.set_velocity(golden24.v)
+        assert sol.solve(starts, tts) == 1 and sol.stats()["kernel_variant"] == 2
     for k, tt in zip(keys, tts):
         assert_bit_equal(tt, golden24.z[f"tt_{k}"], f"{k} gate {speed}/{r0}")
+
+
+def test_converged_box_with_one_finite_unit_reports_no_change(P, oracle):
+    """A star that only moves along z reaches one z-column: every finite cell sits in ONE
+    activity unit, which is exactly the case the distance gate treats as "grown from one
+    source".  Units the gate holds back keep the start active but are not improvements: a
+    second solve of the converged box must return 0 (a reference-style `while (anychange)`
+    driver would otherwise never terminate), and velocities that are not positive finite
+    numbers are refused."""
+    rng = np.random.default_rng(5)
+    shape = (70, 66, 30)        # z is the only axis that fits a wave: it becomes the lane axis
+    v = rng.uniform(0.1, 0.5, size=shape).astype(np.float32)
+    offs = np.array([[0, 0, 1], [0, 0, -1], [0, 0, 2], [0, 0, -2], [1, 1, 1]], np.int32)
+    start = (20, 33, 7)
+    want, _, _ = oracle.converge(v, oracle.make_star(offs), start, order=1)
+    assert np.isinf(want).sum() == want.size - shape[2]
+    for kernel in (2, 1):
+        with P.TravelTimeSolver(shape, P.inputs.make_fs(offs)) as sol:
+            sol.set_option(P.OPT_KERNEL, kernel)
+            sol.set_velocity(v)
+            tt = np.full(shape, np.inf, dtype=np.float32)
+            tt[start] = 0
+            assert sol.solve([start], [tt]) == 1
+            assert_bit_equal(tt, want, f"kernel {kernel}")
+            assert sol.solve([start], [tt]) == 0
+            assert sol.solve([start], [tt]) == 0
+            assert_bit_equal(tt, want, f"kernel {kernel}, re-solved")
+            for bad in (0.0, -1.0, np.nan, np.inf):
+                w = v.copy()
+                w[3, 4, 5] = bad
+                with pytest.raises(P.TTSweepError):
+                    sol.set_velocity(w)
+            with pytest.raises(P.TTSweepError):     # a refused volume is not kept
+                sol.solve([start], [tt])
 
 
 def test_solve_multi_shards_starts_over_devices(P, golden24):

@@ -64,6 +64,7 @@ SYMBOLS = [
 ]
 
 OPT_TIMING, OPT_KERNEL, OPT_MAX_SWEEPS, OPT_MAX_BATCH = 1, 2, 3, 4
+OPT_GATE_SPEED_MILLI, OPT_GATE_R0_MILLI = 5, 6
 KERNEL_AUTO, KERNEL_CELL, KERNEL_STRIP = 0, 1, 2
 
 

@@ -89,6 +89,7 @@ struct ttsweep_ctx {
     int4 *d_unitq = nullptr;                // UNITQ_LISTS lists of unitq_cap entries
     size_t unitq_cap = 0;
     int *d_unitq_ctrl = nullptr;            // UNITQ_CTRL_WORDS (counts, cursors)
+    int nlists = UNITQ_LISTS;               // unit queues = XCDs of the device (census at create)
     int unitq_blocks = 0;                   // persistent grid: workgroups the device holds at once
     std::vector<std::vector<int>> unit_order;       // per start: unit ids, nearest to the start first
     std::vector<long long> unit_order_key;          // start cell the cached order belongs to
@@ -128,6 +129,24 @@ struct ttsweep_ctx {
 static int ctx_bind(const ttsweep_ctx *ctx)
 {
     HIPCHK(hipSetDevice(ctx->device));
+    return 0;
+}
+
+// Counts the XCDs of the device (each has its own L2) by asking many workgroups where they
+// run: the STRIP kernel keeps one unit queue per XCD.  Falls back to 1 queue on any doubt
+// (queues are a locality device, never a correctness one).
+static int count_xcds(ttsweep_ctx *ctx)
+{
+    unsigned *d_seen = nullptr, h_seen = 0;
+    HIPCHK(hipMalloc((void **)&d_seen, sizeof(unsigned)));
+    hipError_t e = hipMemsetAsync(d_seen, 0, sizeof(unsigned), ctx->stream);
+    if (e == hipSuccess) e = launch_xcc_census(d_seen, 4096, ctx->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(&h_seen, d_seen, sizeof(unsigned), hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    (void)hipFree(d_seen);
+    if (e != hipSuccess) return set_error("XCD census failed: %s", hipGetErrorString(e));
+    const int n = __builtin_popcount(h_seen);
+    ctx->nlists = std::min(std::max(n, 1), (int)UNITQ_LISTS);
     return 0;
 }
 
@@ -393,10 +412,11 @@ static int timed_event(ttsweep_ctx *ctx, hipEvent_t *out)
     return 0;
 }
 
-// STRIP work list (static order of the units, input of plan_pass_kernel).  The hardware
-// deals consecutive workgroups round-robin over the 8 XCDs (observed behaviour, used for
-// speed only), and entry i of the list belongs to queue i % 8.  Every active start is
-// given a set of XCDs (one XCD when there are >= 8 starts, several when there are fewer)
+// STRIP work list (static order of the units, input of plan_pass_kernel).  There is one
+// queue per XCD of the device (ctx->nlists, counted at create; 8 on a whole MI355X), a
+// workgroup drains the queue of the XCD it runs on first, and entry i of the list belongs
+// to queue i % nlists.  Every active start is given a set of XCDs (one XCD when there are
+// at least as many starts as XCDs, several when there are fewer)
 // and its units are listed for those XCDs nearest to the start point first.  The units of
 // one start therefore mostly share one L2, and a unit usually runs after the units between
 // it and the start have finished their update of this pass: fresh travel times then cross
@@ -406,7 +426,7 @@ static int build_worklist(ttsweep_ctx *ctx, int nactive)
 {
     const auto t_begin = std::chrono::steady_clock::now();
     const int nunits = strip_units(ctx->L);
-    constexpr int NX = UNITQ_LISTS;
+    const int NX = ctx->nlists;
     std::vector<std::vector<int2>> per_xcd(NX);
     if (nactive >= NX) {
         // XCD x serves starts x, x+8, ...; interleave them rank by rank
@@ -446,7 +466,7 @@ static int build_worklist(ttsweep_ctx *ctx, int nactive)
     if (longest > ctx->unitq_cap) {
         if (ctx->d_unitq) HIPCHK(hipFree(ctx->d_unitq));
         ctx->d_unitq = nullptr;
-        HIPCHK(hipMalloc((void **)&ctx->d_unitq, longest * UNITQ_LISTS * sizeof(int4)));
+        HIPCHK(hipMalloc((void **)&ctx->d_unitq, longest * UNITQ_LISTS * sizeof(int4)));   // (room for 8 lists)
         ctx->unitq_cap = longest;
     }
     if (!ctx->d_unitq_ctrl) HIPCHK(hipMalloc((void **)&ctx->d_unitq_ctrl, (UNITQ_CTRL_WORDS + 1) * sizeof(int)));
@@ -456,11 +476,15 @@ static int build_worklist(ttsweep_ctx *ctx, int nactive)
         const int wgs = 2 * std::max(prop.multiProcessorCount, 1);     // 2 workgroups (8 waves) per CU:
             // measured optimum - a third one adds no throughput, lengthens every unit and lets
             // fewer units see their neighbours' updates of the same pass
-        ctx->unitq_blocks = ((wgs + UNITQ_LISTS - 1) / UNITQ_LISTS) * UNITQ_LISTS;
+        ctx->unitq_blocks = ((wgs + ctx->nlists - 1) / ctx->nlists) * ctx->nlists;
     }
+#ifdef TTSWEEP_DEBUG_ENV
     if (getenv("TTSWEEP_TRACE"))
         fprintf(stderr, "ttsweep work list for %d starts: %.0f us\n", nactive,
                 std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_begin).count());
+#else
+    (void)t_begin;
+#endif
     return 0;
 }
 
@@ -505,8 +529,8 @@ static int launch_pass(ttsweep_ctx *ctx, int nactive, int nstart, int *d_changed
     if (ctx->timing && timed_event(ctx, &e0)) return -1;
     if (ctx->kernel == TTSWEEP_KERNEL_STRIP) {
         HIPCHK(launch_plan_pass(ctx->L, ctx->d_starts, ctx->d_worklist, ctx->worklist_len, d_changed,
-                                ctx->d_unitq, (int)ctx->unitq_cap, ctx->d_unitq_ctrl, ctx->plan,
-                                ctx->pass_index & 1, gate_r2(ctx), ctx->stream));
+                                ctx->d_unitq, (int)ctx->unitq_cap, ctx->nlists, ctx->d_unitq_ctrl,
+                                ctx->plan, ctx->pass_index & 1, gate_r2(ctx), ctx->stream));
         UnitPassTail tail;
         tail.active = ctx->d_active;
         tail.nactive = nactive;
@@ -517,7 +541,7 @@ static int launch_pass(ttsweep_ctx *ctx, int nactive, int nstart, int *d_changed
         tail.changed_host = h_changed_slot;
         tail.changed_next = d_changed_next;
         HIPCHK(launch_sweep_units(ctx->L, ctx->d_v, ctx->d_starts, ctx->d_unitq, (int)ctx->unitq_cap,
-                                  ctx->d_unitq_ctrl, ctx->unitq_blocks, d_changed, ctx->d_strip_cols,
+                                  ctx->nlists, ctx->d_unitq_ctrl, ctx->unitq_blocks, d_changed, ctx->d_strip_cols,
                                   ctx->plan, ctx->pass_index & 1, tail, ctx->stream));
     } else {
         HIPCHK(launch_sweep_cell(ctx->L, ctx->d_v, ctx->d_starts, ctx->d_active, nactive,
@@ -529,6 +553,9 @@ static int launch_pass(ttsweep_ctx *ctx, int nactive, int nstart, int *d_changed
     ctx->pass_index++;
     return 0;
 }
+
+static int solve_device_body(ttsweep_ctx *ctx, int nstart, const ttsweep_start *starts,
+                             float *const *tt_dev, int init);
 
 // ---------------------------------------------------------------------------
 // C ABI
@@ -592,14 +619,8 @@ ttsweep_ctx *ttsweep_create(int device, int nx, int ny, int nz, const ttsweep_fs
     ctx->radius = pull_star_radius(ctx->pull);
     ctx->gate_speed = std::max(1.0, 0.5 * ctx->radius);
     ctx->gate_r0 = ctx->radius + 1.0;
-    if (const char *env = getenv("TTSWEEP_GATE_SPEED")) ctx->gate_speed = atof(env);    // experiments
-    if (const char *env = getenv("TTSWEEP_GATE_R0")) ctx->gate_r0 = atof(env);
     ctx->relax_per_sweep = ttsweep_relaxations_per_sweep(nx, ny, nz, fs, starstart, starstop);
     ctx->kernel = strip_supported(ctx) ? TTSWEEP_KERNEL_STRIP : TTSWEEP_KERNEL_CELL;
-    if (const char *env = getenv("TTSWEEP_KERNEL")) {
-        const int k = atoi(env);
-        if (k == TTSWEEP_KERNEL_CELL || (k == TTSWEEP_KERNEL_STRIP && strip_supported(ctx))) ctx->kernel = k;
-    }
     if (ctx->kernel == TTSWEEP_KERNEL_STRIP) make_layout_strip(ctx);
     else make_layout_cell(ctx);
 
@@ -616,7 +637,8 @@ ttsweep_ctx *ttsweep_create(int device, int nx, int ny, int nz, const ttsweep_fs
         ttsweep_destroy(ctx);
         return nullptr;
     }
-    if (upload_star(ctx) || (ctx->kernel == TTSWEEP_KERNEL_STRIP && upload_strip_plan(ctx))) {
+    if (count_xcds(ctx) || upload_star(ctx)
+        || (ctx->kernel == TTSWEEP_KERNEL_STRIP && upload_strip_plan(ctx))) {
         ttsweep_destroy(ctx);
         return nullptr;
     }
@@ -691,6 +713,14 @@ int ttsweep_set_option(ttsweep_ctx *ctx, int key, long long value)
         if (value < 0) return set_error("max batch must be >= 0");
         ctx->max_batch = (int)value;
         return 0;
+    case TTSWEEP_OPT_GATE_SPEED_MILLI:
+        if (value < 0) return set_error("gate speed must be >= 0");
+        ctx->gate_speed = (double)value / 1000.0;
+        return 0;
+    case TTSWEEP_OPT_GATE_R0_MILLI:
+        if (value < 0) return set_error("gate start radius must be >= 0");
+        ctx->gate_r0 = (double)value / 1000.0;
+        return 0;
     default: return set_error("unknown option %d", key);
     }
 }
@@ -699,8 +729,19 @@ int ttsweep_set_velocity_device(ttsweep_ctx *ctx, const float *v_dev)
 {
     if (!ctx || !v_dev) return set_error("null argument");
     if (ctx_bind(ctx)) return -1;
+    // every cell must be a positive finite number (positive delays: SURVEY.md section 8-a)
+    if (ensure_capacity(ctx, 1)) return -1;
+    unsigned long long *d_bad = ctx->d_work, h_bad = 0;
+    const long long n = (long long)ctx->nx * ctx->ny * ctx->nz;
+    HIPCHK(hipMemsetAsync(d_bad, 0, sizeof(unsigned long long), ctx->stream));
+    HIPCHK(launch_count_bad_velocity(v_dev, n, d_bad, ctx->stream));
+    HIPCHK(hipMemcpyAsync(&h_bad, d_bad, sizeof h_bad, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(launch_pack(ctx->L, v_dev, ctx->d_v, 0.0f, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
+    if (h_bad) {
+        ctx->have_v = false;
+        return set_error("velocity volume holds %llu cells that are not positive finite numbers", h_bad);
+    }
     ctx->have_v = true;
     return 0;
 }
@@ -712,10 +753,12 @@ int ttsweep_set_velocity(ttsweep_ctx *ctx, const float *v_host)
     const size_t bytes = (size_t)ctx->nx * ctx->ny * ctx->nz * sizeof(float);
     float *tmp = nullptr;
     HIPCHK(hipMalloc((void **)&tmp, bytes));
-    hipError_t e = hipMemcpy(tmp, v_host, bytes, hipMemcpyHostToDevice);
+    // copy and consumer kernels are ordered by the same stream
+    hipError_t e = hipMemcpyAsync(tmp, v_host, bytes, hipMemcpyHostToDevice, ctx->stream);
     int rc = 0;
     if (e != hipSuccess) rc = set_error("velocity upload failed: %s", hipGetErrorString(e));
-    else rc = ttsweep_set_velocity_device(ctx, tmp);
+    else rc = ttsweep_set_velocity_device(ctx, tmp);     // (synchronises the stream)
+    (void)hipStreamSynchronize(ctx->stream);
     (void)hipFree(tmp);
     return rc;
 }
@@ -733,16 +776,36 @@ int ttsweep_solve_device(ttsweep_ctx *ctx, int nstart, const ttsweep_start *star
     ctx->stats.kernel_variant = ctx->kernel;
     ctx->ev_used = 0;
     if (nstart == 0) return 0;
+    for (int s = 0; s < nstart; s++)        // before anything is queued on the stream
+        if (starts[s].i < 0 || starts[s].i >= ctx->nx || starts[s].j < 0 || starts[s].j >= ctx->ny
+            || starts[s].k < 0 || starts[s].k >= ctx->nz)
+            return set_error("start %d (%d,%d,%d) outside the grid", s, starts[s].i, starts[s].j, starts[s].k);
     if (ensure_capacity(ctx, nstart)) return -1;
+    const int rc = solve_device_body(ctx, nstart, starts, tt_dev, init);
+    if (rc < 0) {
+        // A failed launch, copy or convergence cap leaves passes queued and the pass state
+        // half-updated: drain the stream (keeping the first error's text) and put the
+        // context back into its between-solves state so that it can be used again.
+        const std::string first = g_last_error;
+        (void)hipStreamSynchronize(ctx->stream);
+        if (ctx->d_unitq_ctrl)
+            (void)hipMemset(ctx->d_unitq_ctrl, 0, (UNITQ_CTRL_WORDS + 1) * sizeof(int));
+        ctx->pass_index = 0;
+        g_last_error = first;
+    }
+    return rc;
+}
 
+} // extern "C"
+
+static int solve_device_body(ttsweep_ctx *ctx, int nstart, const ttsweep_start *starts,
+                             float *const *tt_dev, int init)
+{
     const DevLayout &L = ctx->L;
     HIPCHK(hipEventRecord(ctx->ev_solve0, ctx->stream));
 
     for (int s = 0; s < nstart; s++) {
         const int u[3] = {starts[s].i, starts[s].j, starts[s].k};
-        if (u[0] < 0 || u[0] >= ctx->nx || u[1] < 0 || u[1] >= ctx->ny || u[2] < 0
-            || u[2] >= ctx->nz)
-            return set_error("start %d (%d,%d,%d) outside the grid", s, u[0], u[1], u[2]);
         StartDesc &sd = ctx->h_starts[s];
         sd.T = ctx->d_T + (size_t)s * L.cells;
         sd.sa = u[L.perm[0]];
@@ -797,7 +860,11 @@ int ttsweep_solve_device(ttsweep_ctx *ctx, int nstart, const ttsweep_start *star
     // passes.  A start whose pass-k words show no change is converged; the pass k+1
     // that was launched speculatively for it finds all its units inactive.
     std::vector<int> sweeps(nstart, 0);
+#ifdef TTSWEEP_DEBUG_ENV
     const bool trace = getenv("TTSWEEP_TRACE") != nullptr;
+#else
+    const bool trace = false;
+#endif
     unsigned long long trace_prev = 0, trace_prev_un = 0;
     std::vector<int> snapshot[PASS_SLOTS];      // active starts of each pass in flight
     int nactive = nstart, launched = 0, processed = 0;
@@ -845,8 +912,8 @@ int ttsweep_solve_device(ttsweep_ctx *ctx, int nstart, const ttsweep_start *star
         bool dropped = false;
         for (int s : snapshot[slot]) {
             sweeps[s]++;
-            if (hch[s]) {
-                anychange_ever = true;
+            if (hch[s]) {           // improved, or units still held back by the gate
+                if (hch[s] & CHANGED_IMPROVED) anychange_ever = true;
                 if (sweeps[s] >= ctx->max_sweeps)
                     return set_error("start %d did not converge in %lld sweeps", s, ctx->max_sweeps);
             } else {
@@ -899,6 +966,8 @@ int ttsweep_solve_device(ttsweep_ctx *ctx, int nstart, const ttsweep_start *star
     return anychange_ever ? 1 : 0;
 }
 
+extern "C" {
+
 int ttsweep_solve(ttsweep_ctx *ctx, int nstart, const ttsweep_start *starts,
                   float *const *tt_host)
 {
@@ -923,25 +992,43 @@ int ttsweep_solve(ttsweep_ctx *ctx, int nstart, const ttsweep_start *starts,
         const int n = std::min(batch, nstart - first);
         float *stage = nullptr;
         HIPCHK(hipMalloc((void **)&stage, (size_t)n * cells * sizeof(float)));
+        // The caller's boxes are pinned for the duration of the batch (the reference's CUDA
+        // host does the same, cuda/cudasweep-tt-multistart.cu:273-277): the copies then run at
+        // the full PCIe rate and are ordered on the library's stream with the kernels that
+        // consume / produce the staged boxes.  Where pinning is refused the copies still
+        // work (the runtime stages them).
         std::vector<float *> ptrs(n);
+        std::vector<char> pinned(n, 0);
         int rc = 0;
-        for (int s = 0; s < n && rc == 0; s++) {
+        for (int s = 0; s < n; s++) {
             ptrs[s] = stage + (size_t)s * cells;
-            hipError_t e = hipMemcpy(ptrs[s], tt_host[first + s], cells * sizeof(float),
-                                     hipMemcpyHostToDevice);
+            if (hipHostRegister(tt_host[first + s], cells * sizeof(float), hipHostRegisterDefault) == hipSuccess)
+                pinned[s] = 1;
+            else
+                (void)hipGetLastError();
+        }
+        for (int s = 0; s < n && rc == 0; s++) {
+            hipError_t e = hipMemcpyAsync(ptrs[s], tt_host[first + s], cells * sizeof(float),
+                                          hipMemcpyHostToDevice, ctx->stream);
             if (e != hipSuccess) rc = set_error("travel-time upload failed: %s", hipGetErrorString(e));
         }
         if (rc == 0) rc = ttsweep_solve_device(ctx, n, starts + first, ptrs.data(), 0);
         if (rc >= 0) {
             for (int s = 0; s < n; s++) {
-                hipError_t e = hipMemcpy(tt_host[first + s], ptrs[s], cells * sizeof(float),
-                                         hipMemcpyDeviceToHost);
+                hipError_t e = hipMemcpyAsync(tt_host[first + s], ptrs[s], cells * sizeof(float),
+                                              hipMemcpyDeviceToHost, ctx->stream);
                 if (e != hipSuccess) {
                     rc = set_error("travel-time download failed: %s", hipGetErrorString(e));
                     break;
                 }
             }
         }
+        {
+            hipError_t e = hipStreamSynchronize(ctx->stream);
+            if (e != hipSuccess && rc >= 0) rc = set_error("travel-time transfer failed: %s", hipGetErrorString(e));
+        }
+        for (int s = 0; s < n; s++)
+            if (pinned[s]) (void)hipHostUnregister(tt_host[first + s]);
         (void)hipFree(stage);
         if (rc < 0) return rc;
         any |= rc;

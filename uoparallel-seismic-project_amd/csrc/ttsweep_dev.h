@@ -102,8 +102,13 @@ __host__ __device__ inline int strip_btiles(const DevLayout &L) { return (L.n[1]
 __host__ __device__ inline int strip_cstrips(const DevLayout &L) { return (L.n[2] + STRIP_K - 1) / STRIP_K; }
 __host__ __device__ inline int strip_units(const DevLayout &L) { return L.n[0] * strip_btiles(L) * strip_cstrips(L); }
 
-// Unit queues of one pass (sweep_units_kernel): 8 lists, one per XCD, filled by
-// plan_pass_kernel.  ctrl[0..7] = entries in list x, ctrl[8..15] = next entry to hand out.
+// "changed" word of a start and pass: bit 0 = a travel time improved, bit 1 = units are held
+// back by the distance gate (the start is not converged, but nothing has improved for it).
+enum : int { CHANGED_IMPROVED = 1, CHANGED_PENDING = 2 };
+
+// Unit queues of one pass (sweep_units_kernel): one list per XCD of the device (at most
+// UNITQ_LISTS; the count is measured at run time), filled by plan_pass_kernel.
+// ctrl[0..7] = entries in list x, ctrl[8..15] = next entry to hand out.
 constexpr int UNITQ_LISTS = 8;
 constexpr int UNITQ_CTRL_WORDS = 2 * UNITQ_LISTS;       // followed by one "workgroups done" word
 

@@ -17,6 +17,12 @@ hipError_t launch_unpack(const DevLayout &L, const float *padded, float *user,
 hipError_t launch_init_tt(const DevLayout &L, float *padded, long long sidx,
                           hipStream_t st);
 
+// ---- device census / input check -------------------------------------------
+// *seen |= 1 << (XCD id) for every workgroup of an `nblocks`-workgroup launch
+hipError_t launch_xcc_census(unsigned *seen, int nblocks, hipStream_t st);
+// *bad += cells of the caller's n-cell velocity volume that are not positive and finite
+hipError_t launch_count_bad_velocity(const float *v, long long n, unsigned long long *bad, hipStream_t st);
+
 // ---- sweep, variant CELL ---------------------------------------------------
 // One chaotic in-place pull pass over the whole grid for the `nactive` starts
 // listed in `active`; changed[s] is OR-ed with 1 when any cell of start s
@@ -50,10 +56,10 @@ hipError_t launch_validate(const DevLayout &L, const float *v, const float *T, l
 // sweep_units: a persistent grid (`nblocks` workgroups) drains the queues, own XCD first.
 size_t units_lds_bytes(const StripPlan &plan, int nb);
 hipError_t launch_plan_pass(const DevLayout &L, const StartDesc *starts, const int2 *work,
-                            long long nwork, int *changed, int4 *lists, int list_cap, int *ctrl,
-                            const StripPlan &plan, int parity, float gate_r2, hipStream_t st);
+                            long long nwork, int *changed, int4 *lists, int list_cap, int nlists,
+                            int *ctrl, const StripPlan &plan, int parity, float gate_r2, hipStream_t st);
 hipError_t launch_sweep_units(const DevLayout &L, const float *v, const StartDesc *starts,
-                              const int4 *lists, int list_cap, int *ctrl, int nblocks,
+                              const int4 *lists, int list_cap, int nlists, int *ctrl, int nblocks,
                               int *changed, const StripCol *cols, const StripPlan &plan,
                               int parity, const UnitPassTail &tail, hipStream_t st);
 // First activity flags of a start: from_box = false: only the start's unit is a source;

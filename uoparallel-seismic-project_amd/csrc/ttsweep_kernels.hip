@@ -102,6 +102,52 @@ hipError_t launch_init_tt(const DevLayout &L, float *padded, long long sidx, hip
 }
 
 // ===========================================================================
+// XCD census
+// ===========================================================================
+// Which XCD (accelerator complex die, own L2) a wave runs on: HW_REG_XCC_ID (id 20), bits 3:0.
+__device__ __forceinline__ unsigned xcc_id()
+{
+    return __builtin_amdgcn_s_getreg((4 - 1) << 11 | 0 << 6 | 20) & 0xfu;
+}
+
+// Every workgroup reports the XCD it landed on; the host counts the distinct ids (the
+// number of per-XCD unit queues follows the device instead of a hard-coded 8).
+__global__ void __launch_bounds__(64) xcc_census_kernel(unsigned *__restrict__ seen)
+{
+    if (threadIdx.x == 0) atomicOr(seen, 1u << xcc_id());
+}
+
+hipError_t launch_xcc_census(unsigned *seen, int nblocks, hipStream_t st)
+{
+    hipLaunchKernelGGL(xcc_census_kernel, dim3(nblocks), dim3(64), 0, st, seen);
+    return hipGetLastError();
+}
+
+// Cells of the caller's velocity volume that are not positive finite numbers (the
+// relaxation assumes positive delays; a NaN would also defeat the
+// kernels' NaN-free arithmetic mode).  Integer test on the bit pattern: this file is
+// compiled with -fno-honor-nans.
+__global__ void __launch_bounds__(256)
+count_bad_velocity_kernel(const float *__restrict__ v, long long n, unsigned long long *__restrict__ bad)
+{
+    unsigned mine = 0;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+        const unsigned bits = __float_as_uint(v[i]);
+        mine += !(bits > 0u && bits < 0x7f800000u);
+    }
+#pragma unroll
+    for (int w = 32; w >= 1; w >>= 1) mine += __shfl_xor(mine, w);
+    if ((threadIdx.x & 63) == 0 && mine) atomicAdd(bad, (unsigned long long)mine);
+}
+
+hipError_t launch_count_bad_velocity(const float *v, long long n, unsigned long long *bad, hipStream_t st)
+{
+    const unsigned nblocks = (unsigned)std::min<long long>((n + 255) / 256, 4096);
+    hipLaunchKernelGGL(count_bad_velocity_kernel, dim3(nblocks), dim3(256), 0, st, v, n, bad);
+    return hipGetLastError();
+}
+
+// ===========================================================================
 // sweep, variant CELL: one thread per cell, pull form, in place
 // ===========================================================================
 //
@@ -164,7 +210,7 @@ sweep_cell_kernel(DevLayout L, const float *__restrict__ v,
         }
     }
     // one atomic per wavefront that improved anything (64-lane ballot)
-    if (__ballot(improved) != 0ull && (threadIdx.x & 63) == 0) atomicOr(&changed[s], 1);
+    if (__ballot(improved) != 0ull && (threadIdx.x & 63) == 0) atomicOr(&changed[s], CHANGED_IMPROVED);
 }
 
 hipError_t launch_sweep_cell(const DevLayout &L, const float *v, const StartDesc *starts,
@@ -580,15 +626,16 @@ hipError_t launch_init_tile_flags(const DevLayout &L, const StartDesc &sd, bool 
 __global__ void __launch_bounds__(256)
 plan_pass_kernel(DevLayout L, const StartDesc *__restrict__ starts, const int2 *__restrict__ work,
                  long long nwork, int *__restrict__ changed, int4 *__restrict__ lists, int list_cap,
-                 int *__restrict__ ctrl, int ra, int btiles, int cstrips, int parity, float gate_r2)
+                 int *__restrict__ ctrl, int nlists, int ra, int btiles, int cstrips, int parity,
+                 float gate_r2)
 {
     // wave W handles 64 consecutive entries of ONE XCD's sub-list, so that a wave-level
     // compaction keeps the work-list order (nearest to the start first) inside a queue
     const int lane = threadIdx.x & 63;
     const long long W = ((long long)blockIdx.x * 256 + threadIdx.x) >> 6;
-    const int x = (int)(W % UNITQ_LISTS);
-    const long long k = (W / UNITQ_LISTS) * 64 + lane;
-    const long long i = k * UNITQ_LISTS + x;
+    const int x = (int)(W % nlists);
+    const long long k = (W / nlists) * 64 + lane;
+    const long long i = k * nlists + x;
     unsigned planes = 0;
     int s = 0, unit = -1;
     if (i < nwork) {
@@ -631,7 +678,7 @@ plan_pass_kernel(DevLayout L, const StartDesc *__restrict__ starts, const int2 *
         const unsigned held = pend[unit];
         if (!open) {
             if (planes & ~held) pend[unit] = held | planes;
-            if (held | planes) atomicOr(&changed[s], 1);       // work is waiting
+            if (held | planes) atomicOr(&changed[s], CHANGED_PENDING);     // work is waiting
             planes = 0;
         } else {
             planes |= held;
@@ -691,7 +738,7 @@ __device__ __forceinline__ void relax_special_cell(const DevLayout &L, const flo
     for (int w = 32; w >= 1; w >>= 1) best = fminf(best, __shfl_xor(best, w));
     if (lane == 0 && best < told) {
         T[ci] = best;
-        atomicOr(&changed[s], 1);
+        atomicOr(&changed[s], CHANGED_IMPROVED);
         const int btiles = strip_btiles(L), cstrips = strip_cstrips(L);
         atomicOr(sd.tile_flags + parity * strip_units(L) + (a * btiles + b / STRIP_TB) * cstrips + c / STRIP_K, FLAG_ALL);
     }
@@ -776,7 +823,7 @@ void prof_dump()
 template <int K>
 __global__ void __launch_bounds__(STRIP_TB *STRIP_NS, 2)
 sweep_units_kernel(DevLayout L, const float *__restrict__ v, const StartDesc *__restrict__ starts,
-                   const int4 *__restrict__ lists, int list_cap, int *__restrict__ ctrl,
+                   const int4 *__restrict__ lists, int list_cap, int nlists, int *__restrict__ ctrl,
                    int *__restrict__ changed, const StripCol *__restrict__ cols, StripPlan plan,
                    int btiles, int cstrips, int parity, UnitPassTail tail)
 {
@@ -824,13 +871,15 @@ sweep_units_kernel(DevLayout L, const float *__restrict__ v, const StartDesc *__
     }
 
     PROF_T(t_k0);
-    const int home = blockIdx.x % UNITQ_LISTS;
+    // own queue first: the one of the XCD this workgroup runs on (speed only: a start's
+    // volumes then stay in one L2; any workgroup may drain any queue)
+    const int home = (int)(xcc_id() % (unsigned)nlists);
     int probe = 0, it = 0;
-    while (probe < UNITQ_LISTS) {
+    while (probe < nlists) {
         // ---- take the next unit of queue q (every wave leaves through the same exit:
         // all queues exhausted)
         PROF_T(t_top);
-        const int q = (home + probe) % UNITQ_LISTS;
+        const int q = (home + probe) % nlists;
         const int n = ctrl[q];
         if (tid == 0) head[it & 1] = ctrl[UNITQ_LISTS + q] < n ? atomicAdd(&ctrl[UNITQ_LISTS + q], 1) : n;
         __syncthreads();
@@ -993,7 +1042,7 @@ sweep_units_kernel(DevLayout L, const float *__restrict__ v, const StartDesc *__
         for (int w = 32; w >= 1; w >>= 1) improved |= __shfl_xor(improved, w);
         if (lane == 0 && improved) {
             atomicOr(sd.tile_flags + parity * nunits + my_unit, improved);
-            atomicOr(&changed[s], 1);
+            atomicOr(&changed[s], CHANGED_IMPROVED);
         }
 #ifdef TTSWEEP_PROFILE
         if (tid == 0) {
@@ -1046,28 +1095,30 @@ size_t units_lds_bytes(const StripPlan &plan, int nb)
 }
 
 hipError_t launch_plan_pass(const DevLayout &L, const StartDesc *starts, const int2 *work,
-                            long long nwork, int *changed, int4 *lists, int list_cap, int *ctrl,
-                            const StripPlan &plan, int parity, float gate_r2, hipStream_t st)
+                            long long nwork, int *changed, int4 *lists, int list_cap, int nlists,
+                            int *ctrl, const StripPlan &plan, int parity, float gate_r2, hipStream_t st)
 {
     if (nwork <= 0) return hipSuccess;
+    if (nlists < 1 || nlists > UNITQ_LISTS) return hipErrorInvalidValue;
     const int btiles = strip_btiles(L);
-    // threads: waves of 64 entries, dealt over the 8 sub-lists
-    const long long per_list = (nwork + UNITQ_LISTS - 1) / UNITQ_LISTS;
-    const long long waves = ((per_list + 63) / 64) * UNITQ_LISTS;
+    // threads: waves of 64 entries, dealt over the sub-lists
+    const long long per_list = (nwork + nlists - 1) / nlists;
+    const long long waves = ((per_list + 63) / 64) * nlists;
     const long long nblocks = (waves + 3) / 4;
     if (nblocks > 0x7fffffffLL) return hipErrorInvalidValue;
     hipLaunchKernelGGL(plan_pass_kernel, dim3((unsigned)nblocks), dim3(256), 0, st, L, starts, work,
-                       nwork, changed, lists, list_cap, ctrl, plan.ra, btiles, strip_cstrips(L),
+                       nwork, changed, lists, list_cap, ctrl, nlists, plan.ra, btiles, strip_cstrips(L),
                        parity, gate_r2);
     return hipGetLastError();
 }
 
 hipError_t launch_sweep_units(const DevLayout &L, const float *v, const StartDesc *starts,
-                              const int4 *lists, int list_cap, int *ctrl, int nblocks,
+                              const int4 *lists, int list_cap, int nlists, int *ctrl, int nblocks,
                               int *changed, const StripCol *cols, const StripPlan &plan,
                               int parity, const UnitPassTail &tail, hipStream_t st)
 {
-    if (nblocks <= 0) return hipErrorInvalidValue;      // the last workgroup closes the pass
+    if (nblocks <= 0 || nlists < 1 || nlists > UNITQ_LISTS)
+        return hipErrorInvalidValue;                    // (the last workgroup closes the pass)
     const int btiles = strip_btiles(L);
     auto kern = sweep_units_kernel<STRIP_K>;
     const size_t lds = units_lds_bytes(plan, L.n[1]);
@@ -1077,7 +1128,7 @@ hipError_t launch_sweep_units(const DevLayout &L, const float *v, const StartDes
         if (e != hipSuccess) return e;
     }
     hipLaunchKernelGGL(kern, dim3((unsigned)nblocks), dim3(STRIP_TB, STRIP_NS), lds, st, L, v, starts,
-                       lists, list_cap, ctrl, changed, cols, plan, btiles, strip_cstrips(L), parity, tail);
+                       lists, list_cap, nlists, ctrl, changed, cols, plan, btiles, strip_cstrips(L), parity, tail);
     return hipGetLastError();
 }
 

@@ -26,6 +26,13 @@ def _check(rc: int, what: str) -> int:
     return rc
 
 
+def _require(cond: bool, what: str):
+    """Argument checks that must survive `python -O` (a wrong shape, dtype or device handed
+    to the C ABI is an out-of-bounds or cross-device access on the GPU)."""
+    if not cond:
+        raise TTSweepError(what)
+
+
 def device_count() -> int:
     return _check(_lib.lib().ttsweep_device_count(), "ttsweep_device_count")
 
@@ -95,15 +102,22 @@ class TravelTimeSolver:
         """v: numpy float32 [nx,ny,nz] (host) or a CUDA/HIP torch tensor (device)."""
         if isinstance(v, np.ndarray):
             v = np.ascontiguousarray(v, dtype=np.float32)
-            assert v.shape == self.shape
+            _require(v.shape == self.shape, f"velocity shape {v.shape} != {self.shape}")
             _check(self._L.ttsweep_set_velocity(self._ctx, v.ctypes.data), "ttsweep_set_velocity")
         else:
+            self._require_device_tensor(v, self.shape, "velocity")
             import torch
-            assert v.is_cuda and v.dtype == torch.float32 and v.is_contiguous()
-            assert tuple(v.shape) == self.shape
             torch.cuda.current_stream(v.device).synchronize()
             _check(self._L.ttsweep_set_velocity_device(self._ctx, v.data_ptr()),
                    "ttsweep_set_velocity_device")
+
+    def _require_device_tensor(self, t, shape, what):
+        import torch
+        _require(isinstance(t, torch.Tensor) and t.is_cuda, f"{what}: not a device tensor")
+        _require(t.dtype == torch.float32 and t.is_contiguous(), f"{what}: must be contiguous float32")
+        _require(tuple(t.shape) == tuple(shape), f"{what}: shape {tuple(t.shape)} != {tuple(shape)}")
+        _require(t.device.index == self.device,
+                 f"{what}: tensor on device {t.device.index}, solver on device {self.device}")
 
     # -- the hot path -------------------------------------------------------
     @staticmethod
@@ -118,11 +132,11 @@ class TravelTimeSolver:
         """In-place solve of host boxes (numpy float32 arrays, one per start).
         Returns 1 if anything improved, 0 if all boxes were already converged."""
         arr = self._starts_array(starts)
-        assert len(tt_boxes) == len(arr)
+        _require(len(tt_boxes) == len(arr), "one box per start")
         ptrs = (C.c_void_p * len(arr))()
         for s, box in enumerate(tt_boxes):
-            assert isinstance(box, np.ndarray) and box.dtype == np.float32
-            assert box.flags["C_CONTIGUOUS"] and box.shape == self.shape
+            _require(isinstance(box, np.ndarray) and box.dtype == np.float32, f"box {s}: float32 ndarray")
+            _require(box.flags["C_CONTIGUOUS"] and box.shape == self.shape, f"box {s}: shape / layout")
             ptrs[s] = box.ctypes.data
         return _check(self._L.ttsweep_solve(self._ctx, len(arr), arr, ptrs), "ttsweep_solve")
 
@@ -131,8 +145,7 @@ class TravelTimeSolver:
         [nstart,nx,ny,nz] on this solver's device, written in place."""
         import torch
         arr = self._starts_array(starts)
-        assert tt.is_cuda and tt.dtype == torch.float32 and tt.is_contiguous()
-        assert tuple(tt.shape) == (len(arr),) + self.shape
+        self._require_device_tensor(tt, (len(arr),) + self.shape, "travel-time boxes")
         ptrs = (C.c_void_p * len(arr))()
         stride = tt.stride(0) * 4
         for s in range(len(arr)):
@@ -146,8 +159,7 @@ class TravelTimeSolver:
         [nx,ny,nz]): the reference's store conditions evaluated on the device, and the cells
         no store can have produced; (0, 0, 0) exactly for the converged box."""
         import torch
-        assert tt.is_cuda and tt.dtype == torch.float32 and tt.is_contiguous()
-        assert tuple(tt.shape) == self.shape
+        self._require_device_tensor(tt, self.shape, "travel-time box")
         torch.cuda.current_stream(tt.device).synchronize()
         st = Start(int(start[0]), int(start[1]), int(start[2]))
         a, b, c = C.c_longlong(0), C.c_longlong(0), C.c_longlong(0)
@@ -169,10 +181,11 @@ def solve_multi(devices, v: np.ndarray, fs: np.ndarray, starts, tt_boxes, starst
     if starstop is None:
         starstop = len(fs) - 1
     arr = TravelTimeSolver._starts_array(starts)
-    assert len(tt_boxes) == len(arr)
+    _require(len(tt_boxes) == len(arr), "one box per start")
     ptrs = (C.c_void_p * len(arr))()
     for s, box in enumerate(tt_boxes):
-        assert box.dtype == np.float32 and box.flags["C_CONTIGUOUS"] and box.shape == v.shape
+        _require(box.dtype == np.float32 and box.flags["C_CONTIGUOUS"] and box.shape == v.shape,
+                 f"box {s}: float32, C order, shape of the velocity volume")
         ptrs[s] = box.ctypes.data
     dev = (C.c_int * len(devices))(*devices)
     nx, ny, nz = v.shape
@@ -186,7 +199,8 @@ def sweepXYZ(v: np.ndarray, tt: np.ndarray, fs: np.ndarray, start, starstart: in
     """The one-call drop-in (ttsweep_sweepXYZ): converge `tt` in place on device 0."""
     v = np.ascontiguousarray(v, dtype=np.float32)
     fs = np.ascontiguousarray(fs, dtype=FS_DTYPE)
-    assert tt.dtype == np.float32 and tt.flags["C_CONTIGUOUS"] and tt.shape == v.shape
+    _require(tt.dtype == np.float32 and tt.flags["C_CONTIGUOUS"] and tt.shape == v.shape,
+             "tt: float32, C order, shape of the velocity volume")
     if starstop is None:
         starstop = len(fs) - 1
     nx, ny, nz = v.shape
