@@ -5,29 +5,40 @@ serial_new/sweep-tt-multistart.c) on MI355X.
   python bench.py --gpus 1 --steps K --warmup W
   python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
 
-Workload (BASELINE.json metric config): synthetic 241x241x51 velocity volume
-(the real model is absent from the reference tree), the reference's default
-818-offset star (docs/818-FS.txt, serial_new/Makefile:15) and the 24 start points
-of docs/start-24-241-241-51.txt.  One "step" = one complete multi-start solve:
-initialise every travel-time box on the device (all INFINITY, start 0), relax to
-convergence, and - for N > 1 - gather all boxes on rank 0 over RCCL.  The starts
-are sharded round-robin over the N ranks (strong scaling: the 24 starts are the
-fixed total work); inputs are resident in HBM when the timed region starts.
+Default workload (BASELINE.json metric config): synthetic 241x241x51 velocity volume (the
+real model is absent from the reference tree), the reference's default 818-offset star
+(docs/818-FS.txt, serial_new/Makefile:15) and the 24 start points of
+docs/start-24-241-241-51.txt.  One "step" = one complete multi-start solve: initialise
+every travel-time box on the device (all INFINITY, start 0), relax to convergence, and -
+for N > 1 - gather all boxes on rank 0 over RCCL.  The starts are sharded over the N ranks
+(strong scaling: the 24 starts are the fixed total work); inputs are resident in HBM when
+the timed region starts.  Other workloads (parity-test configurations of BASELINE.json, the
+HBM-regime run `--star six --grid 1024,1024,512 --starts 111 --nstarts 14`) are selected
+with --grid / --star / --starts / --nstarts; every label in the line is derived from them.
 
-metric: Mcells*sweeps/s = (cells relaxed against the whole forward star, summed
-over passes and starts) / wall seconds / 1e6; one full sweep of one start relaxes
-`cells` cells, so for a schedule that skips nothing this is cells x sweeps / s.
-The GPU schedule skips units whose inputs did not change and holds far units back until
-final values can reach them, so it executes fewer cell-relaxations than full sweeps
-would; those skipped cells are NOT counted.
-Passes of different schedules are the same work per cell but not the same
-progress, so ms_per_step (time to the converged solution) is the number to
-compare across schedules and against the CPU.
+value: Mcells*sweeps/s = (cells relaxed against the whole forward star, summed over passes
+and starts) / wall seconds / 1e6.  The GPU schedules relax only what can change, so this is
+NOT comparable across schedules; `time_to_solution` (seconds to the converged boxes, GPU
+measured, CPU extrapolated from measured seconds per reference sweep x the recorded
+reference sweep counts) is.
+
+roofline: the roof that binds the dominant kernel.  Per cell*pass the path moves 12
+compulsory bytes (read v, read T, write T) and does 4 flops (add, mul, add, min) per star
+offset: above ~10 flops per byte (every shipped star) the vector ALUs bind ("valu": fp32
+vector flops against 256 CU x 4 SIMD x 32 lanes x 2.4 GHz), below it HBM does ("hbm").
+`roofline_hbm` always carries the HBM view the BASELINE metric names.  `traffic` = bytes
+that crossed the L2's memory side per launch, measured IN THIS RUN by two rocprofv3 --pmc
+child passes (FETCH_SIZE, WRITE_SIZE; gfx950 read correction x2) of the same workload.
 """
 import argparse
+import csv
+import glob
 import json
 import os
+import shutil
+import subprocess
 import sys
+import tempfile
 import time
 
 import numpy as np
@@ -36,14 +47,29 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0               # MI355X_MICROARCH.md: 8.0 TB/s spec
-VALU_PEAK_TLANEOPS = 78.6           # 256 CU x 4 SIMD x 32 lanes/clk x 2.4 GHz (SIMD-32)
+VALU_PEAK_TFLOPS = 78.6             # 256 CU x 4 SIMD x 32 lanes/clk x 2.4 GHz, one flop per lane-op (no FMA:
+                                    # the reference rounds the multiply and the add separately)
 BYTES_PER_CELL_SWEEP = 12           # read v, read tt, write tt
-LANEOPS_PER_RELAX = 4               # add, mul, add, min
+FLOPS_PER_RELAX = 4                 # add, mul, add, min
+BALANCE_FLOPS_PER_BYTE = VALU_PEAK_TFLOPS * 1e12 / (HBM_PEAK_GBS * 1e9)
+
+
+def usable_cores():
+    """Host cores this process may really use: the affinity mask, capped by the cgroup's CPU
+    quota where one is set (a container can see 256 cores and own 16)."""
+    n = len(os.sched_getaffinity(0))
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    return n
 
 
 def cpu_baseline(P, v, offs, start, sweeps=4):
-    """The CPU restatement of serial_new (oracle/, kind "port") timed on this
-    host: `sweeps` reference-order passes of one start from the initial state."""
+    """The CPU restatement of serial_new (oracle/, kind "port") timed on this host:
+    `sweeps` reference-order passes of one start from the initial state."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import oracle as O
     O.build()
@@ -54,16 +80,15 @@ def cpu_baseline(P, v, offs, start, sweeps=4):
         O.sweep(v, tt, fs, start)
     dt = time.perf_counter() - t0
     return {"value": v.size * sweeps / dt / 1e6, "unit": "Mcells*sweeps/s", "cores": 1,
-            "kind": "port", "seconds": round(dt, 2),
+            "kind": "port", "seconds": round(dt, 2), "seconds_per_sweep": dt / sweeps,
             "sample": f"{sweeps} reference-order passes of start 0 on the same grid/star "
-                      f"(single thread, gcc -O3; host has {os.cpu_count()} logical cores)"}
+                      f"(single thread, gcc -O3; {usable_cores()} usable of {os.cpu_count()} logical cores)"}
 
 
 def cpu_baseline_cores(shape, star, starts_name, ncores, sweeps=1):
     """The same CPU restatement with one start per core (the strategy of the reference's
     mpi/backup.c:351-363), `ncores` processes side by side, each `sweeps` reference-order
     passes of its own start.  Child processes: they never touch the GPU."""
-    import subprocess
     script = os.path.join(ROOT, "oracle", "cpu_sample.py")
     args = [str(n) for n in shape] + [star, starts_name]
     t0 = time.perf_counter()
@@ -79,26 +104,112 @@ def cpu_baseline_cores(shape, star, starts_name, ncores, sweeps=1):
     if len(secs) != ncores:
         return None
     cells = shape[0] * shape[1] * shape[2]
-    # rate while all cores sweep together: each finished `sweeps` passes in its own time
     return {"value": sum(cells * sweeps / t for t in secs) / 1e6, "unit": "Mcells*sweeps/s",
             "cores": ncores, "kind": "port", "seconds": round(max(secs), 2),
+            "seconds_per_sweep_per_core": sum(secs) / len(secs) / sweeps,
             "wall_seconds_incl_startup": round(wall, 2),
             "sample": f"{sweeps} reference-order pass(es) of {ncores} different starts, one process per "
-                      f"core, side by side (host has {os.cpu_count()} logical cores)"}
+                      f"usable core, side by side ({os.cpu_count()} logical cores on the host, "
+                      f"{len(os.sched_getaffinity(0))} in the affinity mask, {usable_cores()} within the CPU quota)"}
 
 
-def measured_traffic():
-    """HBM-side bytes per sweep-kernel launch from the rocprofv3 PMC passes of this same
-    command (FETCH_SIZE and WRITE_SIZE in separate runs, gfx950 x2 read correction),
-    committed under profiles/; bench.py cannot run a profiler around itself."""
-    import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")))
-    if not files:
-        return None
+def reference_sweep_counts(star, starts):
+    """Sweeps the unmodified reference needed per start (recorded with the reference itself,
+    tests/golden/big_digests.json), for the starts that were recorded."""
     try:
-        return float(json.load(open(files[-1]))["bytes_per_launch"])
+        d = json.load(open(os.path.join(ROOT, "tests", "golden", "big_digests.json")))
+    except Exception:
+        return []
+    out = []
+    for i, j, k in starts:
+        rec = d.get(f"syn241_{star}_{i}_{j}_{k}")
+        if rec:
+            out.append(int(rec["sweeps"]))
+    return out
+
+
+def workload_args(args):
+    return ["--grid", args.grid, "--star", args.star, "--starts", args.starts,
+            "--nstarts", str(args.nstarts), "--kernel", str(args.kernel)] + \
+        (["--gate-speed", str(args.gate_speed)] if args.gate_speed is not None else [])
+
+
+def measure_traffic(args, kernel_patterns):
+    """HBM-side bytes per sweep-kernel launch of THIS workload: two child runs of this script
+    under `rocprofv3 --pmc` (FETCH_SIZE and WRITE_SIZE need separate passes), started before
+    this process touches the GPU.  Returns None when the profiler is not usable."""
+    exe = shutil.which("rocprofv3")
+    if exe is None:
+        return None
+    sums, launches = {}, 0
+    env = dict(os.environ, TMPDIR="/tmp")
+    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+        d = tempfile.mkdtemp(prefix="ttsweep_pmc_", dir="/tmp")
+        try:
+            cmd = [exe, "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", d, "--",
+                   sys.executable, os.path.abspath(__file__), "--child", "--steps", "1", "--warmup", "1",
+                   "--no-cpu"] + workload_args(args)
+            r = subprocess.run(cmd, capture_output=True, text=True, timeout=420, env=env, cwd="/tmp")
+            if r.returncode != 0:
+                return None
+            total, n = 0.0, 0
+            for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+                for row in csv.DictReader(open(f)):
+                    if row["Counter_Name"] != counter:
+                        continue
+                    name = row["Kernel_Name"]
+                    if any(p in name for p in kernel_patterns):
+                        total += float(row["Counter_Value"])
+                        n += kernel_patterns[0] in name
+            if n == 0:
+                return None
+            sums[counter], launches = total, n
+        except Exception:
+            return None
+        finally:
+            shutil.rmtree(d, ignore_errors=True)
+    fetch_b = sums["FETCH_SIZE"] * 1024.0 * 2.0      # gfx950: FETCH_SIZE reads half of wide coalesced loads
+    write_b = sums["WRITE_SIZE"] * 1024.0
+    return {"bytes_per_launch": (fetch_b + write_b) / launches, "fetch_bytes_per_launch": fetch_b / launches,
+            "write_bytes_per_launch": write_b / launches, "launches_profiled": launches,
+            "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE child passes of this run "
+                      "(kernels: " + ", ".join(kernel_patterns) + "; read counter x2, gfx950)"}
+
+
+def host_program_end_to_end(P, shape, star, starts, v_host):
+    """The actual drop-in product: the plain-C host program (the reference's main(), vbox /
+    star / start files in, libttsweep.so behind sweepXYZ) on the same workload, output.tt
+    suppressed.  Wall seconds of the whole process and of its sweep loop (host buffers:
+    transfers included)."""
+    exe = os.path.join(ROOT, "uoparallel-seismic-project_amd", "host", "sweep-tt-multistart")
+    if not os.path.exists(exe) or v_host is None:
+        return None
+    d = tempfile.mkdtemp(prefix="ttsweep_host_", dir="/tmp")
+    try:
+        vfile = os.path.join(d, "model.vbox")
+        P.inputs.write_vbox(vfile, v_host, (1, 1, 1))
+        sfile = os.path.join(d, "starts.txt")
+        with open(sfile, "w") as f:
+            f.write(f"{len(starts)}\n" + "".join(f"{i} {j} {k}\n" for i, j, k in starts))
+        env = dict(os.environ, TTSWEEP_NO_OUTPUT="1")
+        t0 = time.perf_counter()
+        r = subprocess.run([exe, vfile, P.inputs.star_path(star), sfile], capture_output=True, text=True,
+                           timeout=600, env=env, cwd=d)
+        wall = time.perf_counter() - t0
+        if r.returncode != 0:
+            return None
+        loop = [ln for ln in r.stdout.splitlines() if ln.startswith("ttsweep: sweep loop")]
+        dev = [ln for ln in r.stdout.splitlines() if "ms on device" in ln]
+        return {"process_wall_seconds": round(wall, 3),
+                "sweep_loop_wall_seconds": float(loop[-1].split()[3]) if loop else None,
+                "device_ms": float(dev[0].split()[-4]) if dev else None,
+                "what": "host/sweep-tt-multistart <vbox> <star> <starts> with TTSWEEP_NO_OUTPUT=1: process start, "
+                        "VBOX load, context creation, pinned host<->device transfers of every box, solve, "
+                        "confirming second driver pass"}
     except Exception:
         return None
+    finally:
+        shutil.rmtree(d, ignore_errors=True)
 
 
 def main():
@@ -111,19 +222,50 @@ def main():
     ap.add_argument("--starts", default="24")
     ap.add_argument("--nstarts", type=int, default=0, help="use only the first N start points")
     ap.add_argument("--kernel", type=int, default=0)
-    ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
+    ap.add_argument("--gate-speed", type=float, default=None, help="schedule knob of the STRIP kernel (cells/pass)")
+    ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline legs")
+    ap.add_argument("--no-traffic", action="store_true", help="skip the rocprofv3 --pmc child passes")
+    ap.add_argument("--no-host", action="store_true", help="skip the host-program end-to-end leg")
+    ap.add_argument("--child", action="store_true", help=argparse.SUPPRESS)     # profiled child of measure_traffic
     ap.add_argument("--backend", default="nccl",
                     help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only to rehearse "
                          "the multi-rank path on a box with fewer GPUs than ranks)")
     args = ap.parse_args()
-
-    import torch
-    import ttsweep_pkg
-    P = ttsweep_pkg.load()
+    if args.child:
+        args.no_cpu = args.no_traffic = args.no_host = True
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+
+    import ttsweep_pkg
+    P = ttsweep_pkg.load()
+    nx, ny, nz = map(int, args.grid.split(","))
+    cells = nx * ny * nz
+    offs = P.inputs.read_triples(P.inputs.star_path(args.star))
+    fs = P.inputs.make_fs(offs)
+    npull = len(P.build_pull_star(fs))
+    starts = P.inputs.read_triples(P.inputs.starts_path(args.starts))
+    if args.nstarts:
+        starts = starts[:args.nstarts]
+    small = (nx, ny, nz) == (241, 241, 51)
+    if not small:
+        starts = P.inputs.scaled_starts(starts, nx, ny, nz)
+    nstart = len(starts)
+    valu_bound = FLOPS_PER_RELAX * npull / BYTES_PER_CELL_SWEEP > BALANCE_FLOPS_PER_BYTE
+    tile_star = npull <= 26 and args.kernel in (0, 3)      # (the library's own choice is read back below)
+    patterns = ["tile_sweep_kernel"] if tile_star else ["sweep_units_kernel", "plan_pass_kernel"]
+
+    # ---- legs that run other processes on the GPU: before this one initialises it
+    traffic = host_e2e = None
+    v_host = P.inputs.velocity_model(nx, ny, nz, 20160507) if small else None
+    if world == 1 and not args.no_traffic:
+        traffic = measure_traffic(args, patterns)
+    if world == 1 and not args.no_host and small:
+        host_e2e = host_program_end_to_end(P, (nx, ny, nz), args.star, starts, v_host)
+
+    import torch
     dist = None
     ndev = torch.cuda.device_count()
     dev_index = local_rank % max(ndev, 1)
@@ -135,39 +277,29 @@ def main():
             dist.init_process_group("nccl", device_id=dev)
         else:
             dist.init_process_group(args.backend)
-    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
 
-    default_workload = (args.grid, args.star, args.starts, args.nstarts, args.kernel) == \
-        ("241,241,51", "818", "24", 0, 0) and world == 1
-    nx, ny, nz = map(int, args.grid.split(","))
-    cells = nx * ny * nz
-    offs = P.inputs.read_triples(P.inputs.star_path(args.star))
-    fs = P.inputs.make_fs(offs)
-    starts = P.inputs.read_triples(P.inputs.starts_path(args.starts))
-    if args.nstarts:
-        starts = starts[:args.nstarts]
-    if (nx, ny, nz) != (241, 241, 51):
-        starts = P.inputs.scaled_starts(starts, nx, ny, nz)
-        v_dev = P.inputs.velocity_model_device(nx, ny, nz, 20160507, dev)
-        v_host = None
-    else:
-        v_host = P.inputs.velocity_model(nx, ny, nz, 20160507)
+    if small:
         v_dev = torch.from_numpy(v_host).to(dev)
-    nstart = len(starts)
-    mine = P.multistart.shard_starts(nstart, world, rank)
+    else:
+        v_dev = P.inputs.velocity_model_device(nx, ny, nz, 20160507, dev)
+    # starts differ in cost (22 to 76 reference sweeps): balance the shards by estimated cost
+    shards = P.multistart.all_shards(nstart, world, starts=starts, shape=(nx, ny, nz))
+    mine = shards[rank]
     my_starts = starts[mine]
 
     sol = P.TravelTimeSolver((nx, ny, nz), fs, device=dev_index)
     if args.kernel:
         sol.set_option(P.OPT_KERNEL, args.kernel)
+    if args.gate_speed is not None:
+        sol.set_option(P.OPT_GATE_SPEED_MILLI, int(round(args.gate_speed * 1000)))
     sol.set_velocity(v_dev)
     tt = torch.empty((len(mine), nx, ny, nz), dtype=torch.float32, device=dev)
 
     def step():
         sol.solve_device(my_starts, tt, init=True)
         if dist is not None and args.backend != "nccl":     # rehearsal: gather through the host
-            return P.multistart.gather_boxes(tt.cpu(), nstart, dist, dst=0)
-        return P.multistart.gather_boxes(tt, nstart, dist, dst=0)
+            return P.multistart.gather_boxes(tt.cpu(), nstart, dist, dst=0, shards=shards)
+        return P.multistart.gather_boxes(tt, nstart, dist, dst=0, shards=shards)
 
     def fence():
         if dist is not None:
@@ -178,7 +310,7 @@ def main():
         step()
     fence()
     t0 = time.perf_counter()
-    sweeps_local = 0            # passes launched (a pass relaxes only the units that are due)
+    sweeps_local = 0            # passes launched (a pass relaxes only what is due)
     relaxed_local = 0           # cells actually relaxed against the whole star
     for _ in range(args.steps):
         step()
@@ -212,14 +344,31 @@ def main():
         launches = max(st["launches"], 1)
         alg_bytes = BYTES_PER_CELL_SWEEP * st["cells_relaxed"]
         relax = st["relaxations_per_sweep"] * (st["cells_relaxed"] / cells)
-        achieved = alg_bytes / kern_s / 1e9 if kern_s > 0 else 0.0
-        lane = LANEOPS_PER_RELAX * relax / kern_s / 1e12 if kern_s > 0 else 0.0
+        flops = FLOPS_PER_RELAX * relax
+        gbs = alg_bytes / kern_s / 1e9 if kern_s > 0 else 0.0
+        tfl = flops / kern_s / 1e12 if kern_s > 0 else 0.0
+        kname = {1: "sweep_cell_kernel", 2: "plan_pass_kernel + sweep_units_kernel (one pass)",
+                 3: "tile_sweep_kernel (one tile hyperplane of an ordering sweep)"}[st["kernel_variant"]]
+        common = {"kernel": kname, "launches": int(launches), "avg_launch_ms": st["sweep_kernel_ms"] / launches,
+                  "algorithmic_bytes_per_launch": alg_bytes / launches,
+                  "algorithmic_flops_per_launch": flops / launches,
+                  "traffic": traffic["bytes_per_launch"] if traffic else None,
+                  "traffic_source": traffic["source"] if traffic else
+                  "not measured in this run (--no-traffic, N > 1, or rocprofv3 unavailable)"}
+        hbm = dict({"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": gbs / HBM_PEAK_GBS}, **common)
+        valu = dict({"bound": "valu", "achieved": tfl, "peak": VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
+                     "frac": tfl / VALU_PEAK_TFLOPS}, **common)
+        per_cell = f"{FLOPS_PER_RELAX * npull} flops per {BYTES_PER_CELL_SWEEP} B per cell*pass " \
+                   f"({npull} offsets; machine balance {BALANCE_FLOPS_PER_BYTE:.1f} flops/B)"
+        hbm["note"] = valu["note"] = per_cell + (": the vector ALUs bind" if valu_bound else ": HBM binds")
+        gpu_s = dt / args.steps
         out = {
-            "metric": "Mcells*sweeps/s (241x241x51, 818-offset star, 24 starts, to convergence)",
+            "metric": f"Mcells*sweeps/s ({nx}x{ny}x{nz}, {len(offs)}-offset star, {nstart} starts, to convergence)",
             "value": relaxed_all / dt / 1e6,
             "unit": "Mcells*sweeps/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": dt / args.steps * 1e3,
+            "ms_per_step": gpu_s * 1e3,
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{nx}x{ny}x{nz} synthetic velocity, {args.star}-FS star, "
@@ -229,26 +378,38 @@ def main():
                        "kernel_variant": st["kernel_variant"],
                        "passes_per_start_mean": sweeps_all / args.steps / nstart,
                        "full_sweep_equivalents_per_start_mean": relaxed_all / cells / args.steps / nstart},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": measured_traffic() if default_workload else None,
-                         "kernel": "sweep", "launches": int(launches),
-                         "avg_launch_ms": st["sweep_kernel_ms"] / launches,
-                         "algorithmic_bytes_per_launch": alg_bytes / launches,
-                         "note": "12 B per cell*pass; with 817 relaxations per cell*pass this star is "
-                                 "VALU-bound, see roofline_valu"},
-            "roofline_valu": {"achieved": lane, "peak": VALU_PEAK_TLANEOPS, "unit": "Tlane-ops/s",
-                              "frac": lane / VALU_PEAK_TLANEOPS,
-                              "relaxations_per_pass": st["relaxations_per_sweep"],
-                              "laneops_per_relaxation": LANEOPS_PER_RELAX},
+            "roofline": valu if valu_bound else hbm,
+            "roofline_hbm": hbm,
+            "time_to_solution": {"gpu_all_starts_s": gpu_s, "gpu_per_start_s": gpu_s / nstart,
+                                 "what": "seconds from initial boxes to converged boxes, all starts batched"},
         }
+        if traffic:
+            out["roofline"]["traffic_detail"] = traffic
+        if host_e2e:
+            out["end_to_end_host_program"] = host_e2e
         if world == 1 and not args.no_cpu and v_host is not None:
-            out["cpu_baseline"] = cpu_baseline(P, v_host, offs, starts[0])
-            ncores = min(16, os.cpu_count() or 1)
+            cb = cpu_baseline(P, v_host, offs, starts[0])
+            out["cpu_baseline"] = cb
+            ncores = usable_cores()
             if ncores > 1:
                 multi = cpu_baseline_cores((nx, ny, nz), args.star, args.starts, ncores)
                 if multi is not None:
                     out["cpu_baseline_all_cores"] = multi
+            ref = reference_sweep_counts(args.star, starts)
+            if ref:
+                mean_sweeps = sum(ref) / len(ref)
+                per_start = cb["seconds_per_sweep"] * mean_sweeps
+                tts_ = out["time_to_solution"]
+                tts_["cpu_per_start_s_extrapolated"] = per_start
+                tts_["cpu_all_starts_one_core_s_extrapolated"] = per_start * nstart
+                if "cpu_baseline_all_cores" in out:
+                    c = out["cpu_baseline_all_cores"]
+                    waves = -(-nstart // c["cores"])
+                    tts_["cpu_all_starts_all_cores_s_extrapolated"] = \
+                        c["seconds_per_sweep_per_core"] * mean_sweeps * waves
+                tts_["cpu_basis"] = (f"measured seconds per reference-order sweep on this host x the sweeps the "
+                                     f"unmodified reference needed (mean {mean_sweeps:.1f} over {len(ref)} of the "
+                                     f"{nstart} starts, tests/golden/big_digests.json); one start per core")
         print(json.dumps(out), flush=True)
     sol.close()
     if dist is not None:

@@ -55,13 +55,14 @@ typedef struct ttsweep_stats {
     int sweeps_max;             /* passes executed for the slowest start */
     long long sweeps_total;     /* sum over starts of passes launched (a pass relaxes only
                                    the units that are due: whose inputs changed and that the
-                                   distance gate has reached) */
+                                   distance gate has reached; TILE kernel: a pass is one
+                                   ordering sweep over the tiles that are due) */
     long long cells_relaxed;    /* cells actually relaxed against the whole star, summed
                                    over passes and starts (= sweeps_total * cells when
                                    nothing is skipped) */
     long long cells;            /* nx*ny*nz */
     long long relaxations_per_sweep; /* in-bounds (cell, offset) pairs one pass relaxes */
-    long long launches;         /* sweep-kernel launches */
+    long long launches;         /* sweep-kernel launches (TILE: one per tile hyperplane of a sweep) */
     double sweep_kernel_ms;     /* sum of sweep-kernel durations (HIP events on the
                                    library's stream; 0 unless timing is enabled) */
     double solve_ms;            /* device time of the whole solve (events) */
@@ -86,6 +87,8 @@ typedef struct ttsweep_ctx ttsweep_ctx;
 #define TTSWEEP_KERNEL_AUTO       0
 #define TTSWEEP_KERNEL_CELL       1   /* one thread per cell, star from global memory */
 #define TTSWEEP_KERNEL_STRIP      2   /* LDS-staged plane slabs, register strips */
+#define TTSWEEP_KERNEL_TILE       3   /* ordered (8-ordering Gauss-Seidel) tile sweeps for small
+                                         stars: the HBM-bound regime */
 
 /* ---- information ------------------------------------------------------- */
 int ttsweep_abi_version(void);
@@ -151,7 +154,8 @@ int ttsweep_validate_device(ttsweep_ctx *ctx, const ttsweep_start *start, const 
 
 /* Multi-GPU form of ttsweep_solve for a host program: the start points are
  * independent (serial_new/...:158-162; mpi/backup.c:351-363 runs one start per
- * rank), so start s is solved on devices[s % ndev]; every device gets its own
+ * rank), so the starts are dealt over the devices, longest first by estimated cost
+ * (distance to the farthest grid corner), at most ceil(nstart / ndev) per device; every device gets its own
  * context and copy of the velocity volume, there is no communication while
  * sweeping, and each device writes its converged boxes straight into the caller's
  * host arrays.  devices may name the same GPU more than once.  Returns 1 / 0 / < 0

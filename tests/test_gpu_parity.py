@@ -42,12 +42,24 @@ def gpu_converge(P, v, fs, starts, starstart=0, starstop=None, tts=None, kernel=
 KERNELS = [pytest.param(1, id="cell"), pytest.param(2, id="strip")]
 
 
-@pytest.mark.parametrize("kernel", KERNELS)
+def tile_supports(offs):
+    """Mirror of the library's rule for the TILE kernel (small stars only)."""
+    pull = {tuple(o) for o in offs[:-1]} | {tuple(-o) for o in offs[:-1]}
+    pull.discard((0, 0, 0))
+    return 0 < len(pull) <= 26 and all(abs(a) <= 2 and abs(b) <= 2 and abs(c) <= 4 for a, b, c in pull)
+
+
+@pytest.mark.parametrize("kernel", KERNELS + [pytest.param(3, id="tile")])
 def test_golden_cases_bit_exact(P, golden, kernel):
     """Every fixture: 5 stars (3 shipped, one non-symmetric, 6-neighbour) x 4 start
-    kinds (interior, corner, dead edge inside / outside the grid), both kernels."""
+    kinds (interior, corner, dead edge inside / outside the grid), every kernel that
+    accepts the star (TILE: the small ones)."""
     n = 0
     for key, sname, offs, start, want, _ in golden.cases():
+        if kernel == 3 and not tile_supports(offs):
+            with pytest.raises(P.TTSweepError):
+                gpu_converge(P, golden.v, P.inputs.make_fs(offs), [start], kernel=kernel)
+            continue
         fs = P.inputs.make_fs(offs)
         (tt,), rc, st = gpu_converge(P, golden.v, fs, [start], kernel=kernel)
         assert rc == 1, key
@@ -55,7 +67,7 @@ def test_golden_cases_bit_exact(P, golden, kernel):
         assert_bit_equal(tt, want, key)
         assert st["sweeps_total"] >= 2
         n += 1
-    assert n == 20
+    assert n == (20 if kernel != 3 else 8)
 
 
 def test_golden_star_subrange(P, golden):
@@ -363,6 +375,74 @@ def test_512_grid_properties(P):
     assert np.isfinite(tt).all() and tt[tuple(starts[0])] == 0 and (tt >= 0).all()
     v = v_dev.cpu().numpy()
     assert sampled_open_edges(v, tt, offs, starts[0], 20000, 2) == 0
+
+
+SHELL26 = np.array([[a, b, c] for a in (-1, 0, 1) for b in (-1, 0, 1) for c in (-1, 0, 1) if (a, b, c) != (0, 0, 0)]
+                   + [[1, 1, 1]], np.int32)       # 26-neighbour shell + the entry the exclusive bound drops
+
+
+@pytest.mark.parametrize("shape,seed", [((33, 70, 19), 31), ((70, 33, 40), 32), ((5, 4, 3), 33), ((1, 1, 1), 34),
+                                        ((2, 100, 2), 35), ((9, 8, 65), 36), ((17, 16, 97), 37)])
+def test_tile_kernel_small_stars_vs_oracle(P, oracle, shape, seed):
+    """TILE kernel (ordered tile sweeps) on ragged / tiny / thin grids with random velocities:
+    the 6-neighbour star, the 26-neighbour shell (diagonal offsets: neighbours on the same
+    hyperplane), and random asymmetric stars within its reach (entries that are live in one
+    direction only: exact liveness path), 1-3 starts, against the CPU oracle."""
+    rng = np.random.default_rng(seed)
+    v = rng.uniform(0.1, 0.5, size=shape).astype(np.float32)
+    six = P.inputs.read_triples(P.inputs.star_path("six"))
+    rnd = np.stack([rng.integers(-2, 3, size=9), rng.integers(-2, 3, size=9), rng.integers(-4, 5, size=9)], axis=1)
+    rnd = rnd[np.any(rnd != 0, axis=1)].astype(np.int32)
+    for name, offs in (("six", six), ("shell26", SHELL26), ("random", rnd)):
+        assert tile_supports(offs), name
+        nstart = int(rng.integers(1, 4))
+        starts = np.stack([rng.integers(0, n, size=nstart) for n in shape], axis=1).astype(np.int32)
+        tts, rc, st = gpu_converge(P, v, P.inputs.make_fs(offs), starts, kernel=3)
+        assert st["kernel_variant"] == 3
+        for start, tt in zip(starts, tts):
+            want, _, _ = oracle.converge(v, oracle.make_star(offs), start, order=1)
+            assert_bit_equal(tt, want, f"{name} {shape} start {start}")
+        # small stars take the TILE kernel by default, and a converged box is left alone
+        tts2, rc2, st2 = gpu_converge(P, v, P.inputs.make_fs(offs), starts, tts=[t.copy() for t in tts])
+        assert rc2 == 0 and st2["kernel_variant"] == 3
+        for a, b in zip(tts, tts2):
+            assert_bit_equal(b, a, f"{name} re-solved")
+
+
+def test_tile_kernel_512_grid_matches_cell_kernel(P):
+    """The HBM-bound regime at size: 6-neighbour star on 512x512x256, two starts.  TILE
+    (ordered sweeps) and CELL (one hop per pass, an independent implementation) agree bit for
+    bit; the device validator finds nothing to improve and nothing too small; a second solve
+    reports no change."""
+    import torch
+    shape = (512, 512, 256)
+    dev = torch.device("cuda:0")
+    v_dev = P.inputs.velocity_model_device(*shape, 20160507, dev)
+    fs = P.inputs.make_fs(P.inputs.read_triples(P.inputs.star_path("six")))
+    starts = P.inputs.scaled_starts(P.inputs.read_triples(P.inputs.starts_path("111")), *shape)[:2]
+    out = {}
+    for kernel in (3, 1):
+        with P.TravelTimeSolver(shape, fs) as sol:
+            sol.set_option(P.OPT_KERNEL, kernel)
+            sol.set_velocity(v_dev)
+            tt = torch.empty((2,) + shape, dtype=torch.float32, device=dev)
+            assert sol.solve_device(starts, tt, init=True) == 1
+            assert sol.stats()["kernel_variant"] == kernel
+            if kernel == 3:
+                for s in range(2):
+                    assert sol.validate_device(starts[s], tt[s]) == (0, 0, 0)
+                assert sol.solve_device(starts, tt, init=False) == 0
+            out[kernel] = tt.clone()
+    assert torch.equal(out[1].view(torch.int32), out[3].view(torch.int32))
+    assert bool(torch.isfinite(out[3]).all()) and float(out[3].min()) == 0.0
+
+
+def test_tile_kernel_1024_grid_six_star(P):
+    """BASELINE.json config 5's "HBM-roofline run": the 6-neighbour star on 1024x1024x512
+    (volumes of 2.2 GB), two starts in one batch, pinned by the device validator (every
+    cell) and by idempotence."""
+    st = _batched_config_check(P, (1024, 1024, 512), 2, star="six")
+    assert st["kernel_variant"] == 3
 
 
 def _batched_config_check(P, shape, nstart, star="818"):

@@ -78,7 +78,7 @@ def test_bench_prints_one_contract_line(pkg):
     import json
     import sys
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "1", "--warmup", "0",
-                        "--nstarts", "2", "--no-cpu"], capture_output=True, text=True, timeout=600)
+                        "--nstarts", "2", "--no-cpu", "--no-traffic"], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout + r.stderr
     lines = [l for l in r.stdout.splitlines() if l.strip()]
     assert len(lines) == 1, r.stdout
@@ -89,11 +89,16 @@ def test_bench_prints_one_contract_line(pkg):
     assert d["n_gpus"] == 1 and d["steps"] == 1 and d["warmup"] == 0 and d["vs_baseline"] is None
     assert d["unit"] == "Mcells*sweeps/s" and d["dtype"] == "f32" and d["data"] == "synthetic"
     assert "workload" in d["config"] and "model" not in d["config"] and d["config"]["starts"] == 2
-    rf = d["roofline"]
-    for key in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
-        assert key in rf, key
-    assert rf["bound"] == "hbm" and rf["peak"] == 8000.0 and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-12
+    assert d["metric"].startswith("Mcells*sweeps/s (241x241x51, 818-offset star, 2 starts")
+    for rf, bound, peak in ((d["roofline"], "valu", 78.6), (d["roofline_hbm"], "hbm", 8000.0)):
+        for key in ("bound", "achieved", "peak", "unit", "frac", "traffic", "traffic_source", "avg_launch_ms"):
+            assert key in rf, key
+        assert rf["bound"] == bound and rf["peak"] == peak and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-12
+    assert d["roofline"]["traffic"] is None         # --no-traffic: nothing is quoted from a file
     assert d["value"] > 0 and d["ms_per_step"] > 0 and "cpu_baseline" not in d
+    assert abs(d["time_to_solution"]["gpu_all_starts_s"] - d["ms_per_step"] / 1e3) < 1e-12
+    e2e = d["end_to_end_host_program"]              # the plain-C host program on the same two starts
+    assert e2e["process_wall_seconds"] > 0 and e2e["sweep_loop_wall_seconds"] > 0
     cells = 241 * 241 * 51
     eq = d["config"]["full_sweep_equivalents_per_start_mean"]
     assert abs(d["value"] - eq * 2 * cells / (d["ms_per_step"] / 1e3) / 1e6) < 1e-6 * d["value"]

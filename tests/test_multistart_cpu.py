@@ -77,6 +77,26 @@ def test_shard_assignment_is_a_partition(pkg):
             assert max(map(len, shards)) - min(map(len, shards)) <= 1
 
 
+def test_cost_balanced_shards(pkg):
+    """With coordinates the starts are dealt longest-first by estimated cost: still a
+    partition with balanced counts, the same on every rank, and the heaviest shard is no
+    heavier than under round-robin (start-24 on 241x241x51 over 8 ranks: 3 starts each)."""
+    M = pkg.multistart
+    shape = (241, 241, 51)
+    starts = pkg.inputs.read_triples(pkg.inputs.starts_path("24"))
+    cost = [M.start_cost(s, shape) for s in starts]
+    assert M.start_cost((0, 0, 50), shape) > M.start_cost((120, 120, 50), shape)
+    for world in (1, 2, 4, 8, 5):
+        shards = M.all_shards(len(starts), world, starts, shape)
+        assert sorted(s for sh in shards for s in sh) == list(range(len(starts)))
+        assert max(map(len, shards)) <= -(-len(starts) // world)
+        assert shards == M.all_shards(len(starts), world, starts, shape)
+        assert [M.shard_starts(len(starts), world, r, starts, shape) for r in range(world)] == shards
+        heaviest = max(sum(cost[s] for s in sh) for sh in shards)
+        rr = max(sum(cost[s] for s in sh) for sh in M.all_shards(len(starts), world))
+        assert heaviest <= rr + 1e-9
+
+
 # --------------------------------------------------------------------------
 # one start on several ranks: star split + all-reduce(min)
 # --------------------------------------------------------------------------

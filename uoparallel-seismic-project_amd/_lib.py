@@ -13,6 +13,8 @@ import subprocess
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB_PATH = os.path.join(CSRC, "libttsweep.so")
+if os.environ.get("TTSWEEP_EXPERIMENT_LIB"):        # tools/exp/*: A/B builds of the same sources
+    LIB_PATH = os.path.abspath(os.environ["TTSWEEP_EXPERIMENT_LIB"])
 
 
 class FS(C.Structure):
@@ -65,7 +67,7 @@ SYMBOLS = [
 
 OPT_TIMING, OPT_KERNEL, OPT_MAX_SWEEPS, OPT_MAX_BATCH = 1, 2, 3, 4
 OPT_GATE_SPEED_MILLI, OPT_GATE_R0_MILLI = 5, 6
-KERNEL_AUTO, KERNEL_CELL, KERNEL_STRIP = 0, 1, 2
+KERNEL_AUTO, KERNEL_CELL, KERNEL_STRIP, KERNEL_TILE = 0, 1, 2, 3
 
 
 def build(verbose: bool = False) -> str:

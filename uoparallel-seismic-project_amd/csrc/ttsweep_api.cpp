@@ -98,7 +98,11 @@ struct ttsweep_ctx {
     // per pass (measured, 818-offset star: 3.5 cells/pass gives the shortest solve).
     double gate_speed = 0.0;                // 0: no gate
     double gate_r0 = 0.0;
-    int *d_tile_flags = nullptr;            // capacity_starts x 2 x tiles
+    // TILE kernel: the star in device axes, halo of the staged image, launch counter
+    TileEntry tile_ent[TILE_MAX_ENT];
+    int tile_nent = 0, tile_R = 1;
+    int tile_epoch = 1;
+    int *d_tile_flags = nullptr;            // capacity_starts x activity words (flag_words)
     unsigned long long *d_work = nullptr;   // capacity_starts
     unsigned long long *h_work = nullptr;   // pinned
     int pass_index = 0;
@@ -217,10 +221,81 @@ static void make_layout_strip(ttsweep_ctx *ctx)
     ctx->plan.rb = L.lo[1];
 }
 
+// Padded layout for the TILE kernel: identity axis order (z stays the stride-1 axis),
+// whole tiles, halo R along x and y, TILE_ZF cells in front of and behind every row so that
+// the staged rows start on 16-byte boundaries.
+static void make_layout_tile(ttsweep_ctx *ctx)
+{
+    DevLayout &L = ctx->L;
+    const int n[3] = {ctx->nx, ctx->ny, ctx->nz};
+    const int t[3] = {TILE_X, TILE_Y, TILE_Z};
+    int r[2] = {1, 1};
+    for (const auto &e : ctx->pull) {
+        r[0] = std::max(r[0], std::abs(e.di));
+        r[1] = std::max(r[1], std::abs(e.dj));
+    }
+    ctx->tile_R = std::max(r[0], r[1]);
+    for (int d = 0; d < 3; d++) {
+        L.perm[d] = d;
+        L.n[d] = n[d];
+        L.un[d] = n[d];
+        L.lo[d] = d < 2 ? ctx->tile_R : TILE_ZF;
+        L.p[d] = tile_count(n[d], t[d]) * t[d] + 2 * L.lo[d];
+    }
+    L.s1 = L.p[2];
+    L.s0 = (long long)L.p[1] * L.p[2];
+    L.cells = L.s0 * L.p[0];
+    ctx->tile_nent = (int)ctx->pull.size();
+    for (int e = 0; e < TILE_MAX_ENT; e++) {
+        TileEntry &te = ctx->tile_ent[e];
+        if (e < ctx->tile_nent) {
+            const ttsweep_pull_entry &p = ctx->pull[e];
+            te = TileEntry{p.di, p.dj, p.dk, p.h, p.flags};
+        } else {
+            te = TileEntry{0, 0, 0, 0.0f, PULL_FWD | PULL_REV};     // no-op: candidate = the cell's own value
+        }
+    }
+}
+
+// Can the TILE kernel handle this star?  (the small stars of the HBM-bound regime: reach of
+// at most 2 cells along x and y, 4 along z, at most 26 pull entries)
+static bool tile_supported(const ttsweep_ctx *ctx)
+{
+    if (ctx->pull.empty() || (int)ctx->pull.size() > TILE_MAX_ENT) return false;
+    for (const auto &e : ctx->pull)
+        if (std::abs(e.di) > TILE_MAX_R || std::abs(e.dj) > TILE_MAX_R || std::abs(e.dk) > TILE_ZF) return false;
+    return true;
+}
+
+static bool kernel_available(const ttsweep_ctx *ctx, int k);
+static void make_layout(ttsweep_ctx *ctx);
+static int auto_kernel(const ttsweep_ctx *ctx);
+
 // Can the STRIP kernel handle this star?  (plane and strip offsets within +-7)
 static bool strip_supported(const ttsweep_ctx *ctx)
 {
     return !ctx->pull.empty() && ctx->radius <= STRIP_MAX_RA && ctx->radius < STRIP_CF;
+}
+
+static bool kernel_available(const ttsweep_ctx *ctx, int k)
+{
+    return k == TTSWEEP_KERNEL_CELL || (k == TTSWEEP_KERNEL_STRIP && strip_supported(ctx))
+        || (k == TTSWEEP_KERNEL_TILE && tile_supported(ctx));
+}
+
+// Small stars: ordered tile sweeps; everything within +-7: LDS-staged unit relaxation;
+// otherwise the per-cell kernel.
+static int auto_kernel(const ttsweep_ctx *ctx)
+{
+    return tile_supported(ctx) ? TTSWEEP_KERNEL_TILE
+         : strip_supported(ctx) ? TTSWEEP_KERNEL_STRIP : TTSWEEP_KERNEL_CELL;
+}
+
+static void make_layout(ttsweep_ctx *ctx)
+{
+    if (ctx->kernel == TTSWEEP_KERNEL_STRIP) make_layout_strip(ctx);
+    else if (ctx->kernel == TTSWEEP_KERNEL_TILE) make_layout_tile(ctx);
+    else make_layout_cell(ctx);
 }
 
 static int upload_strip_plan(ttsweep_ctx *ctx)
@@ -365,7 +440,12 @@ static int upload_star(ttsweep_ctx *ctx)
 
 // Activity words of one start: two parities of unit flags, the held-back plane bits and the
 // number of source units (see plan_pass_kernel).
-static size_t flag_words(const DevLayout &L) { return 3 * (size_t)std::max(strip_units(L), 1) + 4; }
+static size_t flag_words(const DevLayout &L)
+{
+    const size_t strip = 3 * (size_t)std::max(strip_units(L), 1) + 4;
+    const size_t tile = 2 * (size_t)tile_count(L.n[0], TILE_X) * tile_count(L.n[1], TILE_Y) * tile_count(L.n[2], TILE_Z);
+    return std::max(strip, tile);
+}
 
 static int ensure_capacity(ttsweep_ctx *ctx, int nstart)
 {
@@ -473,7 +553,7 @@ static int build_worklist(ttsweep_ctx *ctx, int nactive)
     if (ctx->unitq_blocks == 0) {
         hipDeviceProp_t prop;
         HIPCHK(hipGetDeviceProperties(&prop, ctx->device));
-        const int wgs = 2 * std::max(prop.multiProcessorCount, 1);     // 2 workgroups (8 waves) per CU:
+        const int wgs = units_wgs_per_cu() * std::max(prop.multiProcessorCount, 1);     // 2 workgroups (8 waves) per CU:
             // measured optimum - a third one adds no throughput, lengthens every unit and lets
             // fewer units see their neighbours' updates of the same pass
         ctx->unitq_blocks = ((wgs + ctx->nlists - 1) / ctx->nlists) * ctx->nlists;
@@ -543,6 +623,32 @@ static int launch_pass(ttsweep_ctx *ctx, int nactive, int nstart, int *d_changed
         HIPCHK(launch_sweep_units(ctx->L, ctx->d_v, ctx->d_starts, ctx->d_unitq, (int)ctx->unitq_cap,
                                   ctx->nlists, ctx->d_unitq_ctrl, ctx->unitq_blocks, d_changed, ctx->d_strip_cols,
                                   ctx->plan, ctx->pass_index & 1, tail, ctx->stream));
+    } else if (ctx->kernel == TTSWEEP_KERNEL_TILE) {
+        // one ordering sweep: the tile hyperplanes in stream order, one launch each
+        TileSweep P;
+        P.L = ctx->L;
+        P.v = ctx->d_v;
+        P.starts = ctx->d_starts;
+        P.active = ctx->d_active;
+        P.changed = d_changed;
+        P.nactive = nactive;
+        P.NI = tile_count(ctx->L.n[0], TILE_X);
+        P.NJ = tile_count(ctx->L.n[1], TILE_Y);
+        P.NK = tile_count(ctx->L.n[2], TILE_Z);
+        P.R = ctx->tile_R;
+        const int o = ctx->pass_index & 7;          // the eight orderings in turn
+        P.sx = (o & 1) ? -1 : 1;
+        P.sy = (o & 2) ? -1 : 1;
+        P.sz = (o & 4) ? -1 : 1;
+        P.nent = ctx->tile_nent;
+        for (int e = 0; e < TILE_MAX_ENT; e++) P.ent[e] = ctx->tile_ent[e];
+        const int nsteps = P.NI + P.NJ + P.NK - 2;
+        for (int D = 0; D < nsteps; D++) {
+            P.D = D;
+            P.epoch = ++ctx->tile_epoch;
+            HIPCHK(launch_tile_sweep(P, ctx->stream));
+        }
+        ctx->stats.launches += nsteps - 1;
     } else {
         HIPCHK(launch_sweep_cell(ctx->L, ctx->d_v, ctx->d_starts, ctx->d_active, nactive,
                                  d_changed, ctx->d_cell_entries, ctx->n_cell_entries,
@@ -620,9 +726,8 @@ ttsweep_ctx *ttsweep_create(int device, int nx, int ny, int nz, const ttsweep_fs
     ctx->gate_speed = std::max(1.0, 0.5 * ctx->radius);
     ctx->gate_r0 = ctx->radius + 1.0;
     ctx->relax_per_sweep = ttsweep_relaxations_per_sweep(nx, ny, nz, fs, starstart, starstop);
-    ctx->kernel = strip_supported(ctx) ? TTSWEEP_KERNEL_STRIP : TTSWEEP_KERNEL_CELL;
-    if (ctx->kernel == TTSWEEP_KERNEL_STRIP) make_layout_strip(ctx);
-    else make_layout_cell(ctx);
+    ctx->kernel = auto_kernel(ctx);
+    make_layout(ctx);
 
     bool ok = hipSetDevice(device) == hipSuccess
            && hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) == hipSuccess
@@ -683,16 +788,15 @@ int ttsweep_set_option(ttsweep_ctx *ctx, int key, long long value)
     case TTSWEEP_OPT_TIMING: ctx->timing = value != 0; return 0;
     case TTSWEEP_OPT_KERNEL: {
         int k = (int)value;
-        if (k == TTSWEEP_KERNEL_AUTO) k = strip_supported(ctx) ? TTSWEEP_KERNEL_STRIP : TTSWEEP_KERNEL_CELL;
-        if (k != TTSWEEP_KERNEL_CELL && !(k == TTSWEEP_KERNEL_STRIP && strip_supported(ctx)))
+        if (k == TTSWEEP_KERNEL_AUTO) k = auto_kernel(ctx);
+        if (!kernel_available(ctx, k))
             return set_error("kernel variant %lld not available for this star", value);
         if (k == ctx->kernel) return 0;
         // the padded layout depends on the kernel: rebuild it and drop device copies
         if (ctx_bind(ctx)) return -1;
         HIPCHK(hipStreamSynchronize(ctx->stream));
         ctx->kernel = k;
-        if (k == TTSWEEP_KERNEL_STRIP) make_layout_strip(ctx);
-        else make_layout_cell(ctx);
+        make_layout(ctx);
         HIPCHK(hipFree(ctx->d_v));
         ctx->d_v = nullptr;
         ctx->have_v = false;
@@ -825,6 +929,8 @@ static int solve_device_body(ttsweep_ctx *ctx, int nstart, const ttsweep_start *
         else HIPCHK(launch_pack(L, tt_dev[s], sd.T, INFINITY, ctx->stream));
         if (ctx->kernel == TTSWEEP_KERNEL_STRIP)
             HIPCHK(launch_init_tile_flags(L, sd, /*from_box=*/!init, ctx->stream));
+        if (ctx->kernel == TTSWEEP_KERNEL_TILE)
+            HIPCHK(launch_init_tile_state(L, sd, /*from_box=*/!init, ctx->stream));
         ctx->h_active[s] = s;
     }
     if (ctx->kernel == TTSWEEP_KERNEL_STRIP) {
@@ -847,6 +953,7 @@ static int solve_device_body(ttsweep_ctx *ctx, int nstart, const ttsweep_start *
                           hipMemcpyHostToDevice, ctx->stream));
     HIPCHK(hipMemsetAsync(ctx->d_work, 0, 3 * nstart * sizeof(unsigned long long), ctx->stream));
     ctx->pass_index = 0;
+    ctx->tile_epoch = 1;
     if (ctx->kernel == TTSWEEP_KERNEL_STRIP) {
         if (build_worklist(ctx, nstart)) return -1;
         // the passes keep these cleared themselves from here on
@@ -959,7 +1066,7 @@ static int solve_device_body(ttsweep_ctx *ctx, int nstart, const ttsweep_start *
         ctx->stats.sweeps_max = std::max(ctx->stats.sweeps_max, sweeps[s]);
         // CELL kernel relaxes every cell in every pass; STRIP counts its active tiles
         // (STRIP counts cells x offsets actually relaxed; convert to whole-star cell relaxations)
-        ctx->stats.cells_relaxed += ctx->kernel == TTSWEEP_KERNEL_STRIP
+        ctx->stats.cells_relaxed += ctx->kernel != TTSWEEP_KERNEL_CELL
             ? (long long)(ctx->h_work[3 * s] / std::max<size_t>(ctx->pull.size(), 1))
             : (long long)sweeps[s] * ctx->stats.cells;
     }
@@ -1092,11 +1199,39 @@ int ttsweep_solve_multi(int ndev, const int *devices, int nx, int ny, int nz,
     std::vector<int> rc(ndev, 0);
     std::vector<std::string> err(ndev);
     std::vector<std::thread> workers;
+    // Shards balanced by estimated cost (distance from the start to the farthest corner of
+    // the grid: the number of passes grows with it), longest first onto the least loaded
+    // device, at most ceil(nstart / ndev) starts per device (multistart.all_shards).
+    std::vector<std::vector<int>> shard(ndev);
+    {
+        std::vector<double> cost(nstart), load(ndev, 0.0);
+        std::vector<int> order(nstart);
+        const int n[3] = {nx, ny, nz};
+        for (int s = 0; s < nstart; s++) {
+            const int c[3] = {starts[s].i, starts[s].j, starts[s].k};
+            double d2 = 0;
+            for (int a = 0; a < 3; a++) {
+                const double far = std::max(c[a], n[a] - 1 - c[a]);
+                d2 += far * far;
+            }
+            cost[s] = std::sqrt(d2);
+            order[s] = s;
+        }
+        std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return cost[a] > cost[b]; });
+        const size_t cap = (size_t)(nstart + ndev - 1) / ndev;
+        for (int s : order) {
+            int best = -1;
+            for (int d = 0; d < ndev; d++)
+                if (shard[d].size() < cap && (best < 0 || load[d] < load[best])) best = d;
+            shard[best].push_back(s);
+            load[best] += cost[s];
+        }
+    }
     for (int d = 0; d < ndev; d++) {
         workers.emplace_back([&, d]() {
             std::vector<ttsweep_start> my_starts;
             std::vector<float *> my_boxes;
-            for (int s = d; s < nstart; s += ndev) {        // round-robin shard
+            for (int s : shard[d]) {
                 my_starts.push_back(starts[s]);
                 my_boxes.push_back(tt_host[s]);
             }

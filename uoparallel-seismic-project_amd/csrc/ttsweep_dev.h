@@ -125,4 +125,40 @@ struct UnitPassTail {
     int *changed_next;          // the next pass's device words (cleared at the end)
 };
 
+// ---------------------------------------------------------------------------
+// TILE kernel (ordered tile sweeps for small stars, ttsweep_tile.hip)
+// ---------------------------------------------------------------------------
+constexpr int TILE_X = 8, TILE_Y = 8, TILE_Z = 32;      // cells of a tile along the device axes a, b, c
+constexpr int TILE_ZF = 4;                              // cells staged in front of / behind a tile row (>= max |dc|)
+constexpr int TILE_PITCH = TILE_Z + 2 * TILE_ZF;        // floats per staged row
+constexpr int TILE_QPR = TILE_PITCH / 4;                // float4 per staged row
+constexpr int TILE_MAX_R = 2;                           // max |da|, |db| of the star
+constexpr int TILE_MAX_ENT = 26;                        // pull entries (the 26-neighbour shell)
+
+__host__ __device__ inline int tile_count(int n, int t) { return (n + t - 1) / t; }
+
+struct TileEntry {
+    int da, db, dc;     // offset in device axes
+    float h;            // d / 2
+    int flags;          // PULL_FWD | PULL_REV
+};
+
+// Arguments of one launch of tile_sweep_kernel: the tiles of hyperplane D of a sweep with
+// ordering (sx, sy, sz), for every active start.
+struct TileSweep {
+    DevLayout L;
+    const float *v;
+    const StartDesc *starts;
+    const int *active;      // indices of the active starts
+    int *changed;           // "changed" words of this sweep, per start
+    int nactive;
+    int NI, NJ, NK;         // tiles along a, b, c
+    int R;                  // max |da|, |db| (halo of the staged image along a and b)
+    int sx, sy, sz;         // sweep ordering, +1 / -1 per axis
+    int D;                  // hyperplane: tiles with I' + J' + K' == D (coordinates in sweep direction)
+    int epoch;              // launch number within the solve (>= 2)
+    int nent;               // pull entries in use; ent[nent..] are no-ops (h = 0 onto the cell itself)
+    TileEntry ent[TILE_MAX_ENT];
+};
+
 } // namespace ttsweep

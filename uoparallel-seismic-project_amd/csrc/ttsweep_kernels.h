@@ -55,6 +55,7 @@ hipError_t launch_validate(const DevLayout &L, const float *v, const float *T, l
 // the unit's XCD and clears the unit's flag word of this pass.
 // sweep_units: a persistent grid (`nblocks` workgroups) drains the queues, own XCD first.
 size_t units_lds_bytes(const StripPlan &plan, int nb);
+int units_wgs_per_cu();     // persistent workgroups per CU the unit kernel is built for
 hipError_t launch_plan_pass(const DevLayout &L, const StartDesc *starts, const int2 *work,
                             long long nwork, int *changed, int4 *lists, int list_cap, int nlists,
                             int *ctrl, const StripPlan &plan, int parity, float gate_r2, hipStream_t st);
@@ -66,6 +67,17 @@ hipError_t launch_sweep_units(const DevLayout &L, const float *v, const StartDes
 // from_box = true: every unit that holds a finite travel time is one.
 hipError_t launch_init_tile_flags(const DevLayout &L, const StartDesc &sd, bool from_box,
                                   hipStream_t st);
+
+// ---- sweep, variant TILE ---------------------------------------------------
+// One launch = the tiles of one hyperplane of an ordering sweep (TileSweep), one wavefront
+// per tile; a sweep = the launches D = 0 .. NI + NJ + NK - 3 in stream order.  A tile is
+// relaxed only if one of its 27 neighbours improved since it was last relaxed
+// (StartDesc::tile_flags holds two words per tile).  changed[s] |= 1 when a tile of start s
+// improved: a whole sweep without a change proves convergence.
+size_t tile_lds_bytes(int R);
+hipError_t launch_tile_sweep(const TileSweep &P, hipStream_t st);
+// from_box = false: only the start's tile counts as changed; true: every tile does.
+hipError_t launch_init_tile_state(const DevLayout &L, const StartDesc &sd, bool from_box, hipStream_t st);
 
 #ifdef TTSWEEP_PROFILE
 void prof_dump();        // prints and clears the phase counters of sweep_units_kernel

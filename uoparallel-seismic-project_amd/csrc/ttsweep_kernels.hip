@@ -820,8 +820,16 @@ void prof_dump()
 #define PROF_T(x)
 #endif
 
+#ifndef TTSWEEP_WGS_PER_CU
+#define TTSWEEP_WGS_PER_CU 2        // persistent workgroups per CU (measured optimum)
+#endif
+#ifndef TTSWEEP_WGS_GRID
+#define TTSWEEP_WGS_GRID TTSWEEP_WGS_PER_CU
+#endif
+int units_wgs_per_cu() { return TTSWEEP_WGS_GRID; }
+
 template <int K>
-__global__ void __launch_bounds__(STRIP_TB *STRIP_NS, 2)
+__global__ void __launch_bounds__(STRIP_TB *STRIP_NS, TTSWEEP_WGS_PER_CU)
 sweep_units_kernel(DevLayout L, const float *__restrict__ v, const StartDesc *__restrict__ starts,
                    const int4 *__restrict__ lists, int list_cap, int nlists, int *__restrict__ ctrl,
                    int *__restrict__ changed, const StripCol *__restrict__ cols, StripPlan plan,

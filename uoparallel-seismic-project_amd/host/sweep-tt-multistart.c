@@ -38,6 +38,7 @@
 #include <math.h>
 #include <stdio.h>
 #include <stdlib.h>
+#include <time.h>
 
 #define FSRADIUSMAX 7       /* maximum radius forward star */
 #define FSMAX       818     /* maximum # of points in a forward star */
@@ -166,6 +167,8 @@ int main(int argc, char *argv[])
     numstart_g = numstart;
 
     /* sweep until no change in travel times occur */
+    struct timespec loop_t0, loop_t1;
+    clock_gettime(CLOCK_MONOTONIC, &loop_t0);
     anychange = 1;
     while (anychange) {
         numsweeps++;
@@ -180,6 +183,9 @@ int main(int argc, char *argv[])
         for (s = 0; s < numstart; s++) anychange += changed[s];
         printf("sweep %d finished: anychange = %d\n", numsweeps, anychange);
     }
+    clock_gettime(CLOCK_MONOTONIC, &loop_t1);
+    printf("ttsweep: sweep loop %.6f s wall (context creation, transfers and both driver passes included)\n",
+           (double)(loop_t1.tv_sec - loop_t0.tv_sec) + 1e-9 * (double)(loop_t1.tv_nsec - loop_t0.tv_nsec));
 
     /* compact binary result volumes (optional) */
     if (getenv("TTSWEEP_BINARY_OUTPUT") != NULL) {

@@ -18,27 +18,56 @@ from typing import Callable, List, Sequence
 import numpy as np
 
 
-def shard_starts(nstart: int, world_size: int, rank: int) -> List[int]:
-    """Round-robin assignment: start s goes to rank s % world_size."""
-    return list(range(rank, nstart, world_size))
+def start_cost(start, shape) -> float:
+    """Estimated cost of one start: the distance (cells) from the start to the farthest
+    corner of the grid.  The number of passes a solve needs grows with the longest shortest
+    path, i.e. with this distance (starts of the benchmark workload differ 3.5x in the
+    sweeps the reference itself needs: 22 to 76)."""
+    return float(np.sqrt(sum(max(int(c), int(n) - 1 - int(c)) ** 2 for c, n in zip(start, shape))))
+
+
+def all_shards(nstart: int, world_size: int, starts=None, shape=None) -> List[List[int]]:
+    """Start indices per rank.  Without coordinates: round-robin (start s on rank
+    s % world_size).  With them: longest-first by estimated cost onto the least loaded rank
+    (LPT), every rank holding at most ceil(nstart / world_size) starts so that memory stays
+    balanced; all ranks compute the same assignment from the same inputs."""
+    if starts is None or shape is None or world_size <= 1:
+        return [list(range(r, nstart, world_size)) for r in range(world_size)]
+    cap = -(-nstart // world_size)
+    cost = [start_cost(starts[s], shape) for s in range(nstart)]
+    order = sorted(range(nstart), key=lambda s: (-cost[s], s))
+    shards: List[List[int]] = [[] for _ in range(world_size)]
+    load = [0.0] * world_size
+    for s in order:
+        r = min((r for r in range(world_size) if len(shards[r]) < cap), key=lambda r: (load[r], r))
+        shards[r].append(s)
+        load[r] += cost[s]
+    return [sorted(sh) for sh in shards]
+
+
+def shard_starts(nstart: int, world_size: int, rank: int, starts=None, shape=None) -> List[int]:
+    """This rank's start indices (see all_shards)."""
+    return all_shards(nstart, world_size, starts, shape)[rank]
 
 
 def shard_sizes(nstart: int, world_size: int) -> List[int]:
     return [len(range(r, nstart, world_size)) for r in range(world_size)]
 
 
-def gather_boxes(local, nstart: int, dist=None, dst: int = 0):
+def gather_boxes(local, nstart: int, dist=None, dst: int = 0, shards=None):
     """Gather the per-rank stacks of boxes [n_local, nx, ny, nz] on rank `dst` and
     return them ordered by global start index ([nstart, nx, ny, nz]); other ranks
     return None.  Ranks may hold different numbers of starts; stacks are padded to
-    the largest shard for the collective."""
+    the largest shard for the collective.  `shards`: the assignment in use (all_shards);
+    round-robin when omitted."""
     import torch
 
     if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
         return local
     world, rank = dist.get_world_size(), dist.get_rank()
-    sizes = shard_sizes(nstart, world)
-    nmax = max(sizes)
+    if shards is None:
+        shards = all_shards(nstart, world)
+    nmax = max(len(sh) for sh in shards)
     box_shape = tuple(local.shape[1:])
     send = local
     if local.shape[0] < nmax:
@@ -50,24 +79,25 @@ def gather_boxes(local, nstart: int, dist=None, dst: int = 0):
         dist.gather(send, gather_list=recv, dst=dst)
         out = torch.empty((nstart,) + box_shape, dtype=local.dtype, device=local.device)
         for r in range(world):
-            for n, s in enumerate(shard_starts(nstart, world, r)):
+            for n, s in enumerate(shards[r]):
                 out[s] = recv[r][n]
         return out
     dist.gather(send, gather_list=None, dst=dst)
     return None
 
 
-def solve_sharded(starts: Sequence, solve_fn: Callable, dist=None, dst: int = 0):
+def solve_sharded(starts: Sequence, solve_fn: Callable, dist=None, dst: int = 0, shape=None):
     """Solve this rank's shard with `solve_fn(list_of_starts) -> tensor[n_local,...]`
-    and gather all boxes on rank `dst`.  Returns (all_boxes_or_None, local_boxes)."""
+    and gather all boxes on rank `dst`.  Returns (all_boxes_or_None, local_boxes).  With
+    the grid `shape` the shards are balanced by estimated cost, else dealt round-robin."""
     starts = np.asarray(starts, dtype=np.int32).reshape(-1, 3)
     if dist is None or not dist.is_initialized():
         world, rank = 1, 0
     else:
         world, rank = dist.get_world_size(), dist.get_rank()
-    mine = shard_starts(len(starts), world, rank)
-    local = solve_fn(starts[mine])
-    return gather_boxes(local, len(starts), dist, dst), local
+    shards = all_shards(len(starts), world, starts if shape is not None else None, shape)
+    local = solve_fn(starts[shards[rank]])
+    return gather_boxes(local, len(starts), dist, dst, shards=shards), local
 
 
 # --------------------------------------------------------------------------
