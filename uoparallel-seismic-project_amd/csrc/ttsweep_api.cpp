@@ -102,6 +102,11 @@ struct ttsweep_ctx {
     TileEntry tile_ent[TILE_MAX_ENT];
     int tile_nent = 0, tile_R = 1;
     int tile_epoch = 1;
+    int2 *d_tile_list = nullptr;            // due tiles of the launch in flight
+    size_t tile_list_cap = 0;
+    int *d_tile_ctrl = nullptr;             // (count, cursor) per launch of a sweep
+    size_t tile_ctrl_cap = 0;
+    int tile_blocks = 0;                    // persistent grid of the sweep kernel
     int *d_tile_flags = nullptr;            // capacity_starts x activity words (flag_words)
     unsigned long long *d_work = nullptr;   // capacity_starts
     unsigned long long *h_work = nullptr;   // pinned
@@ -643,10 +648,37 @@ static int launch_pass(ttsweep_ctx *ctx, int nactive, int nstart, int *d_changed
         P.nent = ctx->tile_nent;
         for (int e = 0; e < TILE_MAX_ENT; e++) P.ent[e] = ctx->tile_ent[e];
         const int nsteps = P.NI + P.NJ + P.NK - 2;
+        const size_t need_list = (size_t)P.NJ * P.NK * nactive;
+        if (need_list > ctx->tile_list_cap) {
+            HIPCHK(hipStreamSynchronize(ctx->stream));
+            if (ctx->d_tile_list) HIPCHK(hipFree(ctx->d_tile_list));
+            ctx->d_tile_list = nullptr;
+            HIPCHK(hipMalloc((void **)&ctx->d_tile_list, need_list * sizeof(int2)));
+            ctx->tile_list_cap = need_list;
+        }
+        if ((size_t)nsteps > ctx->tile_ctrl_cap) {
+            HIPCHK(hipStreamSynchronize(ctx->stream));
+            if (ctx->d_tile_ctrl) HIPCHK(hipFree(ctx->d_tile_ctrl));
+            ctx->d_tile_ctrl = nullptr;
+            HIPCHK(hipMalloc((void **)&ctx->d_tile_ctrl, (size_t)nsteps * 2 * sizeof(int)));
+            ctx->tile_ctrl_cap = nsteps;
+        }
+        if (ctx->tile_blocks == 0) {
+            hipDeviceProp_t prop;
+            HIPCHK(hipGetDeviceProperties(&prop, ctx->device));
+            // as many single-wavefront workgroups as the LDS of the device holds at once
+#ifdef TTSWEEP_TILE_WGS_PER_CU
+            const size_t per_cu = TTSWEEP_TILE_WGS_PER_CU;
+#else
+            const size_t per_cu = std::max<size_t>(1, (size_t)(160 * 1024) / tile_lds_bytes(ctx->tile_R));
+#endif
+            ctx->tile_blocks = (int)(per_cu * std::max(prop.multiProcessorCount, 1));
+        }
+        HIPCHK(hipMemsetAsync(ctx->d_tile_ctrl, 0, (size_t)nsteps * 2 * sizeof(int), ctx->stream));
         for (int D = 0; D < nsteps; D++) {
             P.D = D;
             P.epoch = ++ctx->tile_epoch;
-            HIPCHK(launch_tile_sweep(P, ctx->stream));
+            HIPCHK(launch_tile_sweep(P, ctx->d_tile_list, ctx->d_tile_ctrl + 2 * D, ctx->tile_blocks, ctx->stream));
         }
         ctx->stats.launches += nsteps - 1;
     } else {
@@ -768,6 +800,8 @@ void ttsweep_destroy(ttsweep_ctx *ctx)
     (void)hipFree(ctx->d_unitq);
     (void)hipFree(ctx->d_unitq_ctrl);
     (void)hipFree(ctx->d_work);
+    (void)hipFree(ctx->d_tile_list);
+    (void)hipFree(ctx->d_tile_ctrl);
     if (ctx->h_work) (void)hipHostFree(ctx->h_work);
     if (ctx->h_starts) (void)hipHostFree(ctx->h_starts);
     if (ctx->h_active) (void)hipHostFree(ctx->h_active);
@@ -1053,6 +1087,9 @@ static int solve_device_body(ttsweep_ctx *ctx, int nstart, const ttsweep_start *
 
 #ifdef TTSWEEP_PROFILE
     prof_dump();
+#endif
+#ifdef TTSWEEP_TILE_PROFILE
+    if (ctx->kernel == TTSWEEP_KERNEL_TILE) tile_prof_dump();
 #endif
     float ms = 0;
     HIPCHK(hipEventElapsedTime(&ms, ctx->ev_solve0, ctx->ev_solve1));

@@ -128,7 +128,10 @@ struct UnitPassTail {
 // ---------------------------------------------------------------------------
 // TILE kernel (ordered tile sweeps for small stars, ttsweep_tile.hip)
 // ---------------------------------------------------------------------------
-constexpr int TILE_X = 8, TILE_Y = 8, TILE_Z = 32;      // cells of a tile along the device axes a, b, c
+#ifndef TTSWEEP_TILE_Z
+#define TTSWEEP_TILE_Z 32
+#endif
+constexpr int TILE_X = 8, TILE_Y = 8, TILE_Z = TTSWEEP_TILE_Z;      // cells of a tile along the device axes a, b, c
 constexpr int TILE_ZF = 4;                              // cells staged in front of / behind a tile row (>= max |dc|)
 constexpr int TILE_PITCH = TILE_Z + 2 * TILE_ZF;        // floats per staged row
 constexpr int TILE_QPR = TILE_PITCH / 4;                // float4 per staged row

@@ -69,16 +69,22 @@ hipError_t launch_init_tile_flags(const DevLayout &L, const StartDesc &sd, bool 
                                   hipStream_t st);
 
 // ---- sweep, variant TILE ---------------------------------------------------
-// One launch = the tiles of one hyperplane of an ordering sweep (TileSweep), one wavefront
-// per tile; a sweep = the launches D = 0 .. NI + NJ + NK - 3 in stream order.  A tile is
-// relaxed only if one of its 27 neighbours improved since it was last relaxed
-// (StartDesc::tile_flags holds two words per tile).  changed[s] |= 1 when a tile of start s
-// improved: a whole sweep without a change proves convergence.
+// One call = the tiles of one hyperplane of an ordering sweep (TileSweep): tile_plan_kernel
+// lists the due ones - a tile is relaxed only if one of its 27 neighbours improved since it
+// was last relaxed (StartDesc::tile_flags holds two words per tile) - in `list` (room for
+// NJ * NK * nactive entries) and counts them in ctrl[0]; tile_sweep_kernel (`nblocks`
+// persistent single-wavefront workgroups) drains the list through the cursor ctrl[1].  Both
+// words must be zero before the call.  A sweep = the calls D = 0 .. NI + NJ + NK - 3 in
+// stream order.  changed[s] |= 1 when a tile of start s improved: a whole sweep without a
+// change proves convergence.
 size_t tile_lds_bytes(int R);
-hipError_t launch_tile_sweep(const TileSweep &P, hipStream_t st);
+hipError_t launch_tile_sweep(const TileSweep &P, int2 *list, int *ctrl, int nblocks, hipStream_t st);
 // from_box = false: only the start's tile counts as changed; true: every tile does.
 hipError_t launch_init_tile_state(const DevLayout &L, const StartDesc &sd, bool from_box, hipStream_t st);
 
+#ifdef TTSWEEP_TILE_PROFILE
+void tile_prof_dump();   // prints and clears the phase counters of tile_sweep_kernel
+#endif
 #ifdef TTSWEEP_PROFILE
 void prof_dump();        // prints and clears the phase counters of sweep_units_kernel
 #endif

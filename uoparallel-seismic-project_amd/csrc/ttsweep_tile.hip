@@ -12,8 +12,10 @@
 // parallelised over hyperplanes at two levels:
 //   * the grid is cut into tiles of 8 x 8 x 32 cells; all tiles with the same progress
 //     I' + J' + K' (tile coordinates counted in sweep direction) are independent of each
-//     other for a 6-neighbour star and are relaxed by ONE kernel launch, one wavefront per
-//     tile; the launches of a sweep follow each other on the stream;
+//     other for a 6-neighbour star and are relaxed by ONE launch pair: tile_plan_kernel lists
+//     the tiles of the hyperplane that are due (something near them changed since they were
+//     last relaxed), tile_sweep_kernel - a persistent grid of single-wavefront workgroups -
+//     drains the list; the launches of a sweep follow each other on the stream;
 //   * inside a tile, lane (i', j') walks its z-column: in step d it relaxes the cell with
 //     k' = d - i' - j', so every cell sees the values its three upwind neighbours got in
 //     step d - 1 (a systolic hyperplane sweep, 46 steps per tile, no barrier: the tile
@@ -29,6 +31,7 @@
 
 #include <algorithm>
 #include <climits>
+#include <cstdio>
 
 namespace ttsweep {
 
@@ -63,153 +66,297 @@ hipError_t launch_init_tile_state(const DevLayout &L, const StartDesc &sd, bool 
     return hipGetLastError();
 }
 
+// A value the compiler can treat as wave-uniform (it is: every lane holds the same bits).
+// Without this the buffer descriptors below sit in vector registers and every LDS-DMA
+// instruction is wrapped in a "waterfall" loop.
+__device__ __forceinline__ int uni(int x) { return __builtin_amdgcn_readfirstlane(x); }
+template <typename T>
+__device__ __forceinline__ T *uni_ptr(T *p)
+{
+    const unsigned long long u = reinterpret_cast<unsigned long long>(p);
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)u);
+    const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(u >> 32));
+    return reinterpret_cast<T *>(((unsigned long long)hi << 32) | lo);
+}
+
+// ---------------------------------------------------------------------------
+// planning a launch: which tiles of hyperplane D are due
+// ---------------------------------------------------------------------------
+// One thread per (active start, J', K'); the tile is due when one of its 27 neighbours
+// (itself included) improved in or after the epoch it was last relaxed in.  Due tiles are
+// stamped with this epoch and appended to `list` (wave-aggregated); ctrl[0] counts them.
+__global__ void __launch_bounds__(256)
+tile_plan_kernel(TileSweep P, int2 *__restrict__ list, int *__restrict__ ctrl)
+{
+    const int lane = threadIdx.x & 63;
+    const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+    bool due = false;
+    int s = 0, tile = 0;
+    if (t < (long long)P.NJ * P.NK * P.nactive) {
+        unsigned u = (unsigned)t;
+        const int Kp = u % P.NK; u /= P.NK;
+        const int Jp = u % P.NJ; u /= P.NJ;
+        const int Ip = P.D - Jp - Kp;
+        if (Ip >= 0 && Ip < P.NI) {
+            const int I = P.sx > 0 ? Ip : P.NI - 1 - Ip;
+            const int J = P.sy > 0 ? Jp : P.NJ - 1 - Jp;
+            const int K = P.sz > 0 ? Kp : P.NK - 1 - Kp;
+            s = P.active[u];
+            int2 *__restrict__ state = reinterpret_cast<int2 *>(P.starts[s].tile_flags);
+            tile = (I * P.NJ + J) * P.NK + K;
+            const int relaxed = state[tile].x;
+            int newest = INT_MIN;
+#pragma unroll
+            for (int n = 0; n < 27; n++) {      // (all 27 loads in flight together)
+                const int ni = min(max(I + n / 9 - 1, 0), P.NI - 1), nj = min(max(J + (n / 3) % 3 - 1, 0), P.NJ - 1),
+                          nk = min(max(K + n % 3 - 1, 0), P.NK - 1);
+                newest = max(newest, state[(ni * P.NJ + nj) * P.NK + nk].y);
+            }
+            due = newest >= relaxed;
+            if (due) state[tile].x = P.epoch;
+        }
+    }
+    const unsigned long long m = __ballot(due);
+    if (m == 0ull) return;
+    int base = 0;
+    if (lane == __builtin_ctzll(m)) base = atomicAdd(&ctrl[0], __popcll(m));
+    base = __shfl(base, __builtin_ctzll(m));
+    if (due) list[base + __popcll(m & ((1ull << lane) - 1ull))] = make_int2(s, tile);
+}
+
+// -DTTSWEEP_TILE_PROFILE: cycle stamps per phase of a tile, summed over all tiles (tuning aid;
+// the stamps go to a buffer of their own and never into a result)
+#ifdef TTSWEEP_TILE_PROFILE
+__device__ unsigned long long g_tile_prof[8];
+__device__ __forceinline__ long long prof_now()
+{
+    unsigned long long t;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) :: "memory");
+    return (long long)t;
+}
+#define PROF_STAMP(x) const long long x = prof_now()
+void tile_prof_dump()
+{
+    unsigned long long h[8] = {};
+    (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(g_tile_prof), sizeof(h));
+    const double n = (double)std::max<unsigned long long>(h[4], 1);
+    fprintf(stderr, "tile prof (cycles per tile, %llu tiles): setup + DMA issue %.0f  DMA wait %.0f  sweep %.0f  "
+            "store + tail %.0f | busy / resident %.3f\n", h[4], h[0] / n, h[1] / n, h[2] / n, h[3] / n,
+            (double)(h[0] + h[1] + h[2] + h[3]) / (double)std::max<unsigned long long>(h[5], 1));
+    unsigned long long z[8] = {};
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_tile_prof), z, sizeof(z));
+}
+#else
+#define PROF_STAMP(x)
+#endif
+
+// ---------------------------------------------------------------------------
+// relaxing the due tiles: a persistent grid of single-wavefront workgroups
+// ---------------------------------------------------------------------------
+// Read-only tables written before the launch (the start descriptors, the list of due tiles)
+// are read through the scalar cache: uniform addresses in the constant address space become
+// s_load instructions, a few hundred cycles instead of a vector-memory round trip per tile.
+struct TileItem { int s, tile; };        // (an int2 as the planner writes it)
+typedef const __attribute__((address_space(4))) StartDesc *const_start_ptr;
+typedef const __attribute__((address_space(4))) TileItem *const_item_ptr;
+
+// The 6-neighbour star with halo 1, entries in the pull star's order (sorted by offset):
+// image index deltas and everything derived from them are compile-time constants.
+constexpr int SIX_SY = TILE_Y + 2;
+constexpr int SIX_NITER = ((TILE_X + 2) * SIX_SY * TILE_QPR + 63) / 64;
+constexpr int SIX_DEL[6] = {-SIX_SY * TILE_PITCH, -TILE_PITCH, -1, 1, TILE_PITCH, SIX_SY *TILE_PITCH};
+
 // NE: entries relaxed (the star, padded with no-ops); EXACT: some entry is live in one
-// direction only, i.e. liveness has to be evaluated.
-template <int NE, bool EXACT>
+// direction only, i.e. liveness has to be evaluated; SIX: the star is exactly the six axis
+// neighbours (SIX_DEL).
+template <int NE, bool EXACT, bool SIX>
 __global__ void __launch_bounds__(64)
-tile_sweep_kernel(TileSweep P)
+tile_sweep_kernel(TileSweep P, const int2 *__restrict__ list, int *__restrict__ ctrl)
 {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int lane = threadIdx.x;
     const DevLayout &L = P.L;
+    const int count = ctrl[0];
 
-    // ---- which tile: blockIdx -> (start slot, J', K'), I' from the hyperplane
-    unsigned bid = blockIdx.x;
-    const int Kp = bid % P.NK; bid /= P.NK;
-    const int Jp = bid % P.NJ; bid /= P.NJ;
-    const int slot = bid;
-    const int Ip = P.D - Jp - Kp;
-    if (Ip < 0 || Ip >= P.NI) return;
-    const int I = P.sx > 0 ? Ip : P.NI - 1 - Ip;
-    const int J = P.sy > 0 ? Jp : P.NJ - 1 - Jp;
-    const int K = P.sz > 0 ? Kp : P.NK - 1 - Kp;
-    const int s = P.active[slot];
-    const StartDesc sd = P.starts[s];
-    int2 *__restrict__ state = reinterpret_cast<int2 *>(sd.tile_flags);
-    const int tile = (I * P.NJ + J) * P.NK + K;
-
-    // ---- due?  (a stale read of a neighbour's word can only postpone this tile: the word
-    // stays >= our last-relaxed epoch until we have been relaxed after it)
-    int newest = INT_MIN;
-    if (lane < 27) {
-        const int ni = I + lane / 9 - 1, nj = J + (lane / 3) % 3 - 1, nk = K + lane % 3 - 1;
-        if ((unsigned)ni < (unsigned)P.NI && (unsigned)nj < (unsigned)P.NJ && (unsigned)nk < (unsigned)P.NK)
-            newest = state[(ni * P.NJ + nj) * P.NK + nk].y;
-    }
-#pragma unroll
-    for (int w = 16; w >= 1; w >>= 1) newest = max(newest, __shfl_xor(newest, w));
-    newest = __builtin_amdgcn_readfirstlane(newest);
-    if (newest < state[tile].x) return;
-    if (lane == 0) state[tile].x = P.epoch;
-
-    // ---- stage the tile and its halo: rows (x - R .. x + 7 + R, y - R .. y + 7 + R), each
-    // 10 float4 wide (z0 - 4 .. z0 + 35), by LDS-DMA: slot = row * 10 + float4, the image is
-    // linear in slot order, so one wave-instruction fills 1 KiB with 64 arbitrary float4
-    const int R = P.R;
+    const int R = SIX ? 1 : P.R;
     const int SY = TILE_Y + 2 * R;
     const int nslots = (TILE_X + 2 * R) * SY * TILE_QPR;
     const int niter = (nslots + 63) >> 6;
     float *vimg = lds;
     float *timg = lds + niter * 256;            // (a multiple of 1 KiB behind the v image)
-    const long long g0 = (long long)(I * TILE_X + L.lo[0] - R) * L.s0
-                       + (long long)(J * TILE_Y + L.lo[1] - R) * L.s1 + (K * TILE_Z + L.lo[2] - TILE_ZF);
-    {
-        const tile_rsrc rv = tile_make_rsrc(P.v + g0), rt = tile_make_rsrc(sd.T + g0);
-        const unsigned s0b = (unsigned)(L.s0 * 4), s1b = (unsigned)(L.s1 * 4);
-        for (int it = 0; it < niter; it++) {
-            const int sl = min(it * 64 + lane, nslots - 1);
-            const int row = sl / TILE_QPR, q = sl - row * TILE_QPR;
-            const int ri = row / SY, rj = row - ri * SY;
-            const unsigned off = (unsigned)ri * s0b + (unsigned)rj * s1b + (unsigned)q * 16u;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rv, (__attribute__((address_space(3))) void *)(vimg + it * 256),
-                                                     16, (int)off, 0, 0, 0);
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rt, (__attribute__((address_space(3))) void *)(timg + it * 256),
-                                                     16, (int)off, 0, 0, 0);
-        }
-    }
 
-    // ---- per-lane geometry while the loads fly
+    // per-lane geometry (the same for every tile of the launch)
     const int ip = lane >> 3, jp = lane & 7;
     const int ci = P.sx > 0 ? ip : TILE_X - 1 - ip;
     const int cj = P.sy > 0 ? jp : TILE_Y - 1 - jp;
-    const bool xy_ok = I * TILE_X + ci < L.n[0] && J * TILE_Y + cj < L.n[1];
     const int row0 = ((ci + R) * SY + (cj + R)) * TILE_PITCH + TILE_ZF;     // image index of (ci, cj, z = 0)
-    const int z_cells = min(TILE_Z, L.n[2] - K * TILE_Z);                   // cells of the tile inside the grid
-    // image index of the start cell, if it lies inside the image (else an index nothing has)
-    int start_at = -1;
-    {
-        const int ra = sd.sa - I * TILE_X + R, rb = sd.sb - J * TILE_Y + R, rc = sd.sc - K * TILE_Z + TILE_ZF;
-        if ((unsigned)ra < (unsigned)(TILE_X + 2 * R) && (unsigned)rb < (unsigned)SY
-            && (unsigned)rc < (unsigned)TILE_PITCH)
-            start_at = (ra * SY + rb) * TILE_PITCH + rc;
-    }
     int del[NE];
     float hh[NE];
 #pragma unroll
     for (int e = 0; e < NE; e++) {
-        del[e] = (P.ent[e].da * SY + P.ent[e].db) * TILE_PITCH + P.ent[e].dc;
+        del[e] = SIX ? SIX_DEL[e] : (P.ent[e].da * SY + P.ent[e].db) * TILE_PITCH + P.ent[e].dc;
         hh[e] = P.ent[e].h;
     }
+    const unsigned s0b = (unsigned)(L.s0 * 4), s1b = (unsigned)(L.s1 * 4);
+    // staging slots of this lane: (row, float4) -> byte offset inside the tile's region
+    // (the same for every tile: computed once, kept for the first iterations' worth)
+    const int dat = P.sz > 0 ? 1 : -1;
 
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // the image has landed (one wave: no barrier)
+    // Workgroup b starts with entry b; further entries come from the cursor ctrl[1], which
+    // counts from gridDim.x on (a workgroup without a first entry never touches it: hundreds
+    // of idle workgroups hammering one word cost more than a sparse launch's tiles).
+    int next = blockIdx.x;
+    PROF_STAMP(t_begin);
+    while (next < count) {
+        const const_item_ptr ip_ = (const_item_ptr)(list + next);
+        const int s = ip_->s, tile = ip_->tile;
+        // the index after this one: asked for now, needed when this tile's sweep is done
+        int after = 0;
+        if (lane == 0) after = atomicAdd(&ctrl[1], 1) + (int)gridDim.x;
+        PROF_STAMP(t_top);
 
-    // ---- the systolic sweep
-    bool improved = false;
-    for (int d = 0; d < TILE_X + TILE_Y + TILE_Z - 2; d++) {
-        const int kp = d - ip - jp;
-        const int ck = P.sz > 0 ? kp : TILE_Z - 1 - kp;
-        if (xy_ok && (unsigned)kp < (unsigned)TILE_Z && ck < z_cells) {
-            const int at = row0 + ck;
-            const float vc = vimg[at], tc = timg[at];
-            float best = tc;
-#pragma unroll
-            for (int e = 0; e < NE; e++) {
-                const int o = at + del[e];
-                const float sum = vc + vimg[o];
-                const float delay = hh[e] * sum;
-                float cand = delay + timg[o];
-                if (EXACT) {
-                    const int fl = P.ent[e].flags;      // (uniform)
-                    if (fl != (PULL_FWD | PULL_REV)) {  // an edge that exists in one direction only
-                        const bool live = ((fl & PULL_FWD) && at != start_at) || ((fl & PULL_REV) && o != start_at);
-                        cand = live ? cand : __builtin_inff();
-                    }
-                }
-                best = fminf(best, cand);
-            }
-            if (best < tc) {
-                timg[at] = best;
-                improved = true;
+        const const_start_ptr sdp = (const_start_ptr)(P.starts + s);
+        float *const T = sdp->T;
+        int2 *const state = reinterpret_cast<int2 *>(sdp->tile_flags);
+        unsigned long long *const work = sdp->work;
+        const int sa = sdp->sa, sb = sdp->sb, sc = sdp->sc;
+        const int K = tile % P.NK, J = (tile / P.NK) % P.NJ, I = tile / (P.NK * P.NJ);
+
+        // ---- stage the tile and its halo: rows (x - R .. x + 7 + R, y - R .. y + 7 + R), each
+        // 10 float4 wide (z0 - 4 .. z0 + 35), by LDS-DMA: slot = row * 10 + float4, the image is
+        // linear in slot order, so one wave-instruction fills 1 KiB with 64 arbitrary float4
+        const long long g0 = (long long)(I * TILE_X + L.lo[0] - R) * L.s0
+                           + (long long)(J * TILE_Y + L.lo[1] - R) * L.s1 + (K * TILE_Z + L.lo[2] - TILE_ZF);
+        {
+            // (the previous tile's LDS writes have retired before the image is overwritten)
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            const tile_rsrc rv = tile_make_rsrc(P.v + g0), rt = tile_make_rsrc(T + g0);
+            for (int it = 0; it < niter; it++) {
+                const int sl = min(it * 64 + lane, nslots - 1);
+                const int row = sl / TILE_QPR, q = sl - row * TILE_QPR;
+                const int ri = row / SY, rj = row - ri * SY;
+                const unsigned off = (unsigned)ri * s0b + (unsigned)rj * s1b + (unsigned)q * 16u;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rv, (__attribute__((address_space(3))) void *)(vimg + it * 256),
+                                                         16, (int)off, 0, 0, 0);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rt, (__attribute__((address_space(3))) void *)(timg + it * 256),
+                                                         16, (int)off, 0, 0, 0);
             }
         }
-        // the next step reads what this one wrote (other lanes, same wavefront: LDS
-        // operations of a wavefront execute in order; keep the compiler from moving them)
-        __builtin_amdgcn_wave_barrier();
-    }
 
-    // ---- write the tile back if it improved: 64 rows of 8 float4
-    const bool any = __ballot(improved) != 0ull;
-    if (lane == 0) {
-        atomicAdd(sd.work, (unsigned long long)(min(TILE_X, L.n[0] - I * TILE_X) * min(TILE_Y, L.n[1] - J * TILE_Y)
-                                                * z_cells) * (unsigned long long)P.nent);
-        atomicAdd(sd.work + 2, 1ull);
-    }
-    if (!any) return;
-    float *__restrict__ T = sd.T;
-    const long long t0 = (long long)(I * TILE_X + L.lo[0]) * L.s0 + (long long)(J * TILE_Y + L.lo[1]) * L.s1
-                       + (K * TILE_Z + L.lo[2]);
+        // steps in which this lane has a cell of the grid: k' = d - i' - j' in [klo, khi)
+        const bool xy_ok = I * TILE_X + ci < L.n[0] && J * TILE_Y + cj < L.n[1];
+        const int z_cells = min(TILE_Z, L.n[2] - K * TILE_Z);               // cells of the tile inside the grid
+        const int klo = P.sz > 0 ? 0 : TILE_Z - z_cells;
+        const unsigned span = xy_ok ? (unsigned)z_cells : 0u;
+        // image index of the start cell, if it lies inside the image (else an index nothing has)
+        int start_at = -1;
+        if (EXACT) {
+            const int ra = sa - I * TILE_X + R, rb = sb - J * TILE_Y + R, rc = sc - K * TILE_Z + TILE_ZF;
+            if ((unsigned)ra < (unsigned)(TILE_X + 2 * R) && (unsigned)rb < (unsigned)SY
+                && (unsigned)rc < (unsigned)TILE_PITCH)
+                start_at = (ra * SY + rb) * TILE_PITCH + rc;
+        }
+
+        PROF_STAMP(t_issued);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // the image has landed (one wave: no barrier)
+        PROF_STAMP(t_landed);
+
+        // ---- the systolic sweep: lane (i', j') relaxes k' = d - i' - j' in step d
+        bool improved = false;
+        int kp = -ip - jp;
+        int at = row0 + (P.sz > 0 ? kp : TILE_Z - 1 - kp);
+        for (int d = 0; d < TILE_X + TILE_Y + TILE_Z - 2; d++, kp++, at += dat) {
+            if ((unsigned)(kp - klo) < span) {
+                float vc, tc, vo[NE], to[NE];
+                if (SIX) {
+                    // one base register, immediate offsets: the image index of the lowest neighbour
+                    const float *vb = vimg + (at + SIX_DEL[0]);
+                    const float *tb = vb + SIX_NITER * 256;
+                    vc = vb[-SIX_DEL[0]];
+                    tc = tb[-SIX_DEL[0]];
 #pragma unroll
-    for (int it = 0; it < TILE_X * TILE_Y * (TILE_Z / 4) / 64; it++) {
-        const int r = it * 8 + (lane >> 3), q = lane & 7;
-        const int ri = r >> 3, rj = r & 7;
-        const float4 val = *reinterpret_cast<const float4 *>(
-            timg + ((ri + R) * SY + (rj + R)) * TILE_PITCH + TILE_ZF + 4 * q);
-        *reinterpret_cast<float4 *>(T + t0 + (long long)ri * L.s0 + (long long)rj * L.s1 + 4 * q) = val;
+                    for (int e = 0; e < NE; e++) {
+                        vo[e] = vb[SIX_DEL[e] - SIX_DEL[0]];
+                        to[e] = tb[SIX_DEL[e] - SIX_DEL[0]];
+                    }
+                } else {
+                    vc = vimg[at];
+                    tc = timg[at];
+#pragma unroll
+                    for (int e = 0; e < NE; e++) {      // all neighbour reads in flight before the first use
+                        vo[e] = vimg[at + del[e]];
+                        to[e] = timg[at + del[e]];
+                    }
+                }
+                float best = tc;
+#pragma unroll
+                for (int e = 0; e < NE; e++) {
+                    const float sum = vc + vo[e];
+                    const float delay = hh[e] * sum;
+                    float cand = delay + to[e];
+                    if (EXACT) {
+                        const int fl = P.ent[e].flags;      // (uniform)
+                        if (fl != (PULL_FWD | PULL_REV)) {  // an edge that exists in one direction only
+                            const bool live = ((fl & PULL_FWD) && at != start_at)
+                                           || ((fl & PULL_REV) && at + del[e] != start_at);
+                            cand = live ? cand : __builtin_inff();
+                        }
+                    }
+                    best = fminf(best, cand);
+                }
+                if (best < tc) {
+                    timg[at] = best;
+                    improved = true;
+                }
+            }
+            // the next step reads what this one wrote (other lanes, same wavefront: LDS
+            // operations of a wavefront execute in order; keep the compiler from moving them)
+            __builtin_amdgcn_wave_barrier();
+        }
+        PROF_STAMP(t_swept);
+        // the next entry is known by now; taking it here keeps the stores below out of its wait
+        next = uni(after);
+
+        // ---- write the tile back if it improved: 64 rows of 8 float4
+        const bool any = __ballot(improved) != 0ull;
+        if (lane == 0) {
+            atomicAdd(work, (unsigned long long)(min(TILE_X, L.n[0] - I * TILE_X) * min(TILE_Y, L.n[1] - J * TILE_Y)
+                                                 * z_cells) * (unsigned long long)P.nent);
+            atomicAdd(work + 2, 1ull);
+        }
+        if (any) {
+            const long long t0 = (long long)(I * TILE_X + L.lo[0]) * L.s0 + (long long)(J * TILE_Y + L.lo[1]) * L.s1
+                               + (K * TILE_Z + L.lo[2]);
+#pragma unroll
+            for (int it = 0; it < TILE_X * TILE_Y * (TILE_Z / 4) / 64; it++) {
+                constexpr int QR = TILE_Z / 4;      // float4 per interior row
+                const int r = (it * 64 + lane) / QR, q = (it * 64 + lane) % QR;
+                const int ri = r >> 3, rj = r & 7;
+                const float4 val = *reinterpret_cast<const float4 *>(
+                    timg + ((ri + R) * SY + (rj + R)) * TILE_PITCH + TILE_ZF + 4 * q);
+                *reinterpret_cast<float4 *>(T + t0 + (long long)ri * L.s0 + (long long)rj * L.s1 + 4 * q) = val;
+            }
+            if (lane == 0) {
+                state[tile].y = P.epoch;
+                atomicOr(&P.changed[s], CHANGED_IMPROVED);
+            }
+        }
+        // (the image is overwritten by the next tile's loads: every read of it has been
+        // consumed; the stores are in flight and read registers only)
+#ifdef TTSWEEP_TILE_PROFILE
+        if (lane == 0) {
+            const long long t_end = prof_now();
+            atomicAdd(&g_tile_prof[0], (unsigned long long)(t_issued - t_top));
+            atomicAdd(&g_tile_prof[1], (unsigned long long)(t_landed - t_issued));
+            atomicAdd(&g_tile_prof[2], (unsigned long long)(t_swept - t_landed));
+            atomicAdd(&g_tile_prof[3], (unsigned long long)(t_end - t_swept));
+            atomicAdd(&g_tile_prof[4], 1ull);
+        }
+#endif
     }
-    if (lane == 0) {
-        state[tile].y = P.epoch;
-        atomicOr(&P.changed[s], CHANGED_IMPROVED);
-    }
+#ifdef TTSWEEP_TILE_PROFILE
+    if (lane == 0) atomicAdd(&g_tile_prof[5], (unsigned long long)(prof_now() - t_begin));
+#endif
 }
 
 size_t tile_lds_bytes(int R)
@@ -218,20 +365,28 @@ size_t tile_lds_bytes(int R)
     return (size_t)2 * ((nslots + 63) / 64) * 1024;
 }
 
-hipError_t launch_tile_sweep(const TileSweep &P, hipStream_t st)
+hipError_t launch_tile_sweep(const TileSweep &P, int2 *list, int *ctrl, int nblocks, hipStream_t st)
 {
     if (P.nactive <= 0) return hipSuccess;
-    if (P.R < 1 || P.R > TILE_MAX_R || P.nent < 1 || P.nent > TILE_MAX_ENT) return hipErrorInvalidValue;
-    const long long nblocks = (long long)P.NJ * P.NK * P.nactive;
-    if (nblocks > 0x7fffffffLL) return hipErrorInvalidValue;
+    if (P.R < 1 || P.R > TILE_MAX_R || P.nent < 1 || P.nent > TILE_MAX_ENT || nblocks < 1) return hipErrorInvalidValue;
+    const long long cand = (long long)P.NJ * P.NK * P.nactive;
+    if (cand > 0x7fffffffLL) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(tile_plan_kernel, dim3((unsigned)((cand + 255) / 256)), dim3(256), 0, st, P, list, ctrl);
     const size_t lds = tile_lds_bytes(P.R);
+    nblocks = (int)std::min<long long>(nblocks, cand);
     bool exact = false;
     for (int e = 0; e < P.nent; e++) exact |= P.ent[e].flags != (PULL_FWD | PULL_REV);
-#define TILE_LAUNCH(NE, EX) \
-    hipLaunchKernelGGL((tile_sweep_kernel<NE, EX>), dim3((unsigned)nblocks), dim3(64), lds, st, P)
-    if (P.nent <= 6) { if (exact) TILE_LAUNCH(6, true); else TILE_LAUNCH(6, false); }
-    else if (P.nent <= 18) { if (exact) TILE_LAUNCH(18, true); else TILE_LAUNCH(18, false); }
-    else { if (exact) TILE_LAUNCH(TILE_MAX_ENT, true); else TILE_LAUNCH(TILE_MAX_ENT, false); }
+    // the plain 6-neighbour star (entries in the pull star's sorted order) has its own instance
+    static const int six[6][3] = {{-1, 0, 0}, {0, -1, 0}, {0, 0, -1}, {0, 0, 1}, {0, 1, 0}, {1, 0, 0}};
+    bool is_six = P.nent == 6 && P.R == 1 && !exact;
+    for (int e = 0; e < 6 && is_six; e++)
+        is_six = P.ent[e].da == six[e][0] && P.ent[e].db == six[e][1] && P.ent[e].dc == six[e][2];
+#define TILE_LAUNCH(NE, EX, SIX) \
+    hipLaunchKernelGGL((tile_sweep_kernel<NE, EX, SIX>), dim3((unsigned)nblocks), dim3(64), lds, st, P, list, ctrl)
+    if (is_six) TILE_LAUNCH(6, false, true);
+    else if (P.nent <= 6) { if (exact) TILE_LAUNCH(6, true, false); else TILE_LAUNCH(6, false, false); }
+    else if (P.nent <= 18) { if (exact) TILE_LAUNCH(18, true, false); else TILE_LAUNCH(18, false, false); }
+    else { if (exact) TILE_LAUNCH(TILE_MAX_ENT, true, false); else TILE_LAUNCH(TILE_MAX_ENT, false, false); }
 #undef TILE_LAUNCH
     return hipGetLastError();
 }
