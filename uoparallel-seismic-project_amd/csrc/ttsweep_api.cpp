@@ -76,7 +76,7 @@ struct ttsweep_ctx {
     int n_fwd_entries = 0;
 
     // STRIP kernel: (da, db) columns of the star, dead-edge boxes
-    StripCol *d_strip_cols = nullptr;
+    StripItem *d_strip_cols = nullptr;      // items of the star per staged plane (upload_strip_plan)
     StripPlan plan{};
     std::vector<std::array<int, 3>> special_offsets;   // device-axis offsets e: cell start - e owns a dead edge
     bool start_is_special = false;
@@ -307,7 +307,9 @@ static int upload_strip_plan(ttsweep_ctx *ctx)
 {
     const DevLayout &L = ctx->L;
     StripPlan &plan = ctx->plan;
-    std::vector<std::vector<StripCol>> per_plane(2 * plan.ra + 1);
+    // (da, db) columns of the pull star: all offsets that differ only in dc
+    struct Col { int db; unsigned mask; float h[16]; };
+    std::vector<std::vector<Col>> per_da(2 * plan.ra + 1);
     ctx->special_offsets.clear();
     ctx->start_is_special = false;
     for (const auto &e : ctx->pull) {
@@ -315,55 +317,73 @@ static int upload_strip_plan(ttsweep_ctx *ctx)
         const int da = u[L.perm[0]], db = u[L.perm[1]], dc = u[L.perm[2]];
         if (e.flags == PULL_FWD) ctx->start_is_special = true;              // dead when the centre is the start
         if (e.flags == PULL_REV) ctx->special_offsets.push_back({da, db, dc});   // dead when the neighbour is the start
-        std::vector<StripCol> &cols = per_plane[da + plan.ra];
+        std::vector<Col> &cols = per_da[da + plan.ra];
         const int t = dc + STRIP_CF;
-        StripCol *col = nullptr;
+        Col *col = nullptr;
         for (auto &c : cols)
-            if (c.rowoff == db && !(c.mask & (1u << t))) { col = &c; break; }
+            if (c.db == db && !(c.mask & (1u << t))) { col = &c; break; }
         if (!col) {     // (a second column for the same (da,db) only if an offset repeats with another length)
-            cols.push_back(StripCol{});
+            cols.push_back(Col{});
             col = &cols.back();
-            col->rowoff = db;
+            col->db = db;
         }
         col->mask |= 1u << t;
         col->h[t] = e.h;
-        for (int j = 0; j < STRIP_W / 4; j++)      // window floats t .. t+K-1 are read
-            if (4 * j + 3 >= t && 4 * j <= t + STRIP_K - 1) col->chunks |= 1u << j;
     }
-    std::vector<StripCol> flat;
-    for (int ia = 0; ia <= 2 * plan.ra; ia++) {
-        plan.first[ia] = (int)flat.size();
-        plan.nent[ia] = 0;
-        for (const auto &c : per_plane[ia]) plan.nent[ia] += __builtin_popcount(c.mask);
-        // Four shares of nearly equal cost for the unit-queue kernel's waves (longest
-        // processing time first; a column costs its offsets plus a fixed part for the
-        // window loads), each share contiguous in the flat list.
-        std::vector<StripCol> cols = per_plane[ia];
-        std::stable_sort(cols.begin(), cols.end(), [](const StripCol &x, const StripCol &y) {
-            return __builtin_popcount(x.mask) > __builtin_popcount(y.mask);
-        });
-        std::vector<StripCol> share[STRIP_NS];
-        int cost[STRIP_NS] = {};
-        for (const auto &c : cols) {
+    // Items of staged plane p (plane 2A - ra + p of a unit that owns planes 2A, 2A + 1): own
+    // plane j relaxes it with plane offset da = p - ra - j.  Columns of the two own planes with
+    // the same row offset share an item (one window load serves both).
+    plan.nstaged = 2 * plan.ra + STRIP_PLANES;
+    std::vector<StripItem> flat;
+    for (int p = 0; p < plan.nstaged; p++) {
+        plan.first[p] = (int)flat.size();
+        std::vector<StripItem> its;
+        for (int j = 0; j < STRIP_PLANES; j++) {
+            plan.nent[p][j] = 0;
+            const int da = p - plan.ra - j;
+            if (da < -plan.ra || da > plan.ra) continue;
+            for (const Col &c : per_da[da + plan.ra]) {
+                plan.nent[p][j] += __builtin_popcount(c.mask);
+                StripItem *it = nullptr;
+                for (auto &x : its)
+                    if (x.rowoff == c.db && x.mask[j] == 0) { it = &x; break; }
+                if (!it) {
+                    its.push_back(StripItem{});
+                    it = &its.back();
+                    it->rowoff = c.db;
+                }
+                it->mask[j] = c.mask;
+                for (int t = 0; t < 16; t++) it->h[j][t] = c.h[t];
+            }
+        }
+        // Four shares of nearly equal cost for the unit kernel's waves (longest processing
+        // time first; an item costs its offsets plus a fixed part for the window load), each
+        // share contiguous in the flat list.
+        auto cost = [](const StripItem &x) { return __builtin_popcount(x.mask[0]) + __builtin_popcount(x.mask[1]) + 3; };
+        std::stable_sort(its.begin(), its.end(), [&](const StripItem &x, const StripItem &y) { return cost(x) > cost(y); });
+        std::vector<StripItem> share[STRIP_NS];
+        int load[STRIP_NS] = {};
+        for (const auto &x : its) {
             int w = 0;
             for (int k = 1; k < STRIP_NS; k++)
-                if (cost[k] < cost[w]) w = k;
-            share[w].push_back(c);
-            cost[w] += __builtin_popcount(c.mask) + 2;
+                if (load[k] < load[w]) w = k;
+            share[w].push_back(x);
+            load[w] += cost(x);
         }
-        if (cols.size() > 255) return set_error("star has too many columns per plane offset");
-        plan.wsplit[ia][0] = 0;
+        if (its.size() > 255) return set_error("star has too many columns per plane offset");
+        plan.wsplit[p][0] = 0;
         for (int w = 0; w < STRIP_NS; w++) {
             flat.insert(flat.end(), share[w].begin(), share[w].end());
-            plan.wsplit[ia][w + 1] = (unsigned char)(plan.wsplit[ia][w] + share[w].size());
+            plan.wsplit[p][w + 1] = (unsigned char)(plan.wsplit[p][w] + share[w].size());
         }
     }
-    plan.first[2 * plan.ra + 1] = (int)flat.size();
+    plan.first[plan.nstaged] = (int)flat.size();
+    if (flat.size() > 0xffff) return set_error("star has too many columns");
     if (ctx->d_strip_cols) HIPCHK(hipFree(ctx->d_strip_cols));
     ctx->d_strip_cols = nullptr;
     if (!flat.empty()) {
-        HIPCHK(hipMalloc((void **)&ctx->d_strip_cols, flat.size() * sizeof(StripCol)));
-        HIPCHK(hipMemcpy(ctx->d_strip_cols, flat.data(), flat.size() * sizeof(StripCol),
+        HIPCHK(hipMalloc((void **)&ctx->d_strip_cols, flat.size() * sizeof(StripItem)));
+        HIPCHK(hipMemcpy(ctx->d_strip_cols, flat.data(), flat.size() * sizeof(StripItem),
                          hipMemcpyHostToDevice));
     }
     return 0;
@@ -585,10 +605,11 @@ static void order_units(const ttsweep_ctx *ctx, const StartDesc &sd, std::vector
     const int nunits = strip_units(L);
     std::vector<std::pair<long long, int>> key(nunits);
     for (int t = 0; t < nunits; t++) {
-        const int cs = t % cstrips, bt = (t / cstrips) % btiles, a = t / (cstrips * btiles);
+        const int cs = t % cstrips, bt = (t / cstrips) % btiles, A = t / (cstrips * btiles);
         const long long cb = std::min(bt * STRIP_TB + STRIP_TB / 2, L.n[1] - 1);
         const long long cc = std::min(cs * STRIP_K + STRIP_K / 2, L.n[2] - 1);
-        const long long da = a - sd.sa, db = cb - sd.sb, dc = cc - sd.sc;
+        // (distances in half cells: the unit's two planes are centred between them)
+        const long long da = 2 * (STRIP_PLANES * A - sd.sa) + (STRIP_PLANES - 1), db = 2 * (cb - sd.sb), dc = 2 * (cc - sd.sc);
         key[t] = {da * da + db * db + dc * dc, t};
     }
     std::sort(key.begin(), key.end());

@@ -78,29 +78,36 @@ constexpr int STRIP_CF = 8;                         // halo in front of a strip 
 constexpr int STRIP_W = STRIP_K + 2 * STRIP_CF;     // neighbour window per (cell strip, column)
 constexpr int STRIP_MAX_RA = 7;                     // plane offsets handled: |da| <= 7
 
-// One (da, db) column of the pull star: all offsets that differ only in dc.
-struct StripCol {
+// A unit of the STRIP kernel owns TWO neighbouring planes (2A, 2A + 1) of one lane tile and
+// strip: every staged neighbour plane q is used twice, with plane offset q - 2A for the first
+// own plane and q - 2A - 1 for the second.  An item is one slab row offset db of a staged plane
+// together with the offsets (differing only in dc) that either own plane relaxes against it:
+// one register window is loaded per item and serves both planes.
+constexpr int STRIP_PLANES = 2;                         // own planes per unit
+constexpr int STRIP_STAGED = 2 * STRIP_MAX_RA + STRIP_PLANES;   // staged planes per unit, at most
+
+struct StripItem {
     int rowoff;             // db: row offset inside the staged slab
-    unsigned mask;          // bit t (1..15) set: offset dc = t - 8 is present
-    unsigned chunks;        // bit j set: float4 j of the window is needed
+    unsigned mask[STRIP_PLANES];    // bit t (1..15) set: own plane j relaxes offset dc = t - 8
     int pad_;
-    float h[16];            // h[t] = d/2 of offset (da, db, t-8)
+    float h[STRIP_PLANES][16];      // h[j][t] = d/2 of offset (q - 2A - j, db, t - 8)
 };
 
 struct StripPlan {
     int ra, rb;                         // max |da|, max |db| over the star
-    int first[2 * STRIP_MAX_RA + 2];    // columns of plane offset da are [first[da+ra], first[da+ra+1])
-    int nent[2 * STRIP_MAX_RA + 1];     // pull entries (offsets) with plane offset da
-    // unit-queue kernel: the columns of a plane offset are laid out so that wave w of the
-    // workgroup relaxes [first[ia] + wsplit[ia][w], first[ia] + wsplit[ia][w+1]) - four
-    // shares of nearly equal cost
-    unsigned char wsplit[2 * STRIP_MAX_RA + 1][STRIP_NS + 1];
+    int nstaged;                        // 2 ra + STRIP_PLANES: staged plane p is plane 2A - ra + p
+    int first[STRIP_STAGED + 1];        // items of staged plane p are [first[p], first[p+1])
+    int nent[STRIP_STAGED][STRIP_PLANES];   // offsets own plane j relaxes against staged plane p
+    // the items of a staged plane are laid out so that wave w of the workgroup relaxes
+    // [first[p] + wsplit[p][w], first[p] + wsplit[p][w+1]) - four shares of nearly equal cost
+    unsigned char wsplit[STRIP_STAGED][STRIP_NS + 1];
 };
 
-// Unit grid of one start: planes a x lane tiles along b x strips along c.
+// Unit grid of one start: plane pairs along a x lane tiles along b x strips along c.
+__host__ __device__ inline int strip_apairs(const DevLayout &L) { return (L.n[0] + STRIP_PLANES - 1) / STRIP_PLANES; }
 __host__ __device__ inline int strip_btiles(const DevLayout &L) { return (L.n[1] + STRIP_TB - 1) / STRIP_TB; }
 __host__ __device__ inline int strip_cstrips(const DevLayout &L) { return (L.n[2] + STRIP_K - 1) / STRIP_K; }
-__host__ __device__ inline int strip_units(const DevLayout &L) { return L.n[0] * strip_btiles(L) * strip_cstrips(L); }
+__host__ __device__ inline int strip_units(const DevLayout &L) { return strip_apairs(L) * strip_btiles(L) * strip_cstrips(L); }
 
 // "changed" word of a start and pass: bit 0 = a travel time improved, bit 1 = units are held
 // back by the distance gate (the start is not converged, but nothing has improved for it).

@@ -61,7 +61,7 @@ hipError_t launch_plan_pass(const DevLayout &L, const StartDesc *starts, const i
                             int *ctrl, const StripPlan &plan, int parity, float gate_r2, hipStream_t st);
 hipError_t launch_sweep_units(const DevLayout &L, const float *v, const StartDesc *starts,
                               const int4 *lists, int list_cap, int nlists, int *ctrl, int nblocks,
-                              int *changed, const StripCol *cols, const StripPlan &plan,
+                              int *changed, const StripItem *items, const StripPlan &plan,
                               int parity, const UnitPassTail &tail, hipStream_t st);
 // First activity flags of a start: from_box = false: only the start's unit is a source;
 // from_box = true: every unit that holds a finite travel time is one.

@@ -341,18 +341,20 @@ hipError_t launch_validate(const DevLayout &L, const float *v, const float *T, l
 // ===========================================================================
 //
 // Work decomposition (device axes a, b, c; c is stride-1):
-//   unit      = one plane a x 64 cells along b x one strip of STRIP_K cells along c:
-//               what one workgroup relaxes at a time, and the granule of activity tracking
-//   lane      = one b row of the unit: K consecutive c cells, held in registers
-//   wave      = a share of the star's (da, db) columns (the four waves of the workgroup
-//               min-combine their partial results at the end)
-// Each lane keeps acc[K] (best travel time so far) and its own velocities (as register
-// pairs) in registers.  For every plane offset da the workgroup stages the neighbour
-// plane's (64 + 2 rb) x (K + 16) window of v and T into LDS once; then for every (da, db)
-// column of the star a lane reads ONE register window of K + 16 neighbour values (up to
-// 8 ds_read_b128 per array, conflict-free by the odd row pitch) and relaxes all offsets
-// dc of that column against it: each loaded value is reused for up to 15 offsets, which
-// is what keeps the kernel VALU-bound instead of LDS-bound.
+//   unit      = TWO neighbouring planes (2A, 2A+1) x 64 cells along b x one strip of STRIP_K
+//               cells along c: what one workgroup relaxes at a time, and the granule of
+//               activity tracking
+//   lane      = one b row of the unit: K consecutive c cells of either plane, in registers
+//   wave      = a share of the items (slab rows x offset sets) of every staged plane; the
+//               four waves of the workgroup min-combine their partial results at the end
+// Each lane keeps acc[j][K] (best travel time so far) and its own velocities (as register
+// pairs) of both own planes in registers.  The workgroup stages every neighbour plane q
+// the star reaches from either own plane - its (64 + 2 rb) x (K + 16) window of v and T -
+// into LDS once.  For every item (a row offset db of the staged plane) a lane reads ONE
+// register window of K + 16 neighbour values per array (8 ds_read_b128 each) and relaxes
+// against it every offset dc of plane offset q - 2A (into the first own plane) and of plane
+// offset q - 2A - 1 (into the second): a loaded value is reused for up to 30 relaxations,
+// and slab traffic, barriers and per-unit overheads are shared by two planes of output.
 //
 // The relaxation is branch-free: there are no bounds tests (halo cells hold
 // +INF / 0) and no liveness tests.  The few cells that own a dead edge (inside
@@ -360,9 +362,9 @@ hipError_t launch_validate(const DevLayout &L, const float *v, const float *T, l
 
 // The first words of the dynamic LDS region carry workgroup-wide scalars (no static
 // __shared__ object: it would shift the 16-byte alignment of the dynamic base).
-constexpr int STRIP_LDS_HEAD = 16 + 64 + 16;     // words reserved in front of the slabs: 16 scalars, the
-                                            // waves' column ranges per plane offset, the offsets per
-                                            // plane offset (sweep_units_kernel)
+constexpr int STRIP_LDS_HEAD = 16 + 64 + 32;    // words reserved in front of the slabs: 16 scalars, the
+                                            // waves' item ranges per staged plane, the offsets per
+                                            // staged plane and own plane (sweep_units_kernel)
 // slab geometry (bytes): up to 64 + 2*7 rows, rounded up to 8, of 128 B for v, then for T
 constexpr int SLAB_MAX_ROWS8 = (STRIP_TB + 2 * STRIP_MAX_RA + 7) / 8 * 8;
 constexpr int SLAB_T_BYTES = SLAB_MAX_ROWS8 * STRIP_W * 4;
@@ -371,34 +373,20 @@ constexpr int SLAB_BYTES = 2 * SLAB_T_BYTES;
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-// A column descriptor held in scalar registers.
-struct ColRegs {
-    int rowoff;
-    unsigned mask, chunks;
-    float h[16];
-};
+// Read-only tables written before the launch (items of the star, start descriptors, the
+// queues the planner filled) are read through the scalar cache: uniform addresses in the
+// constant address space become s_load instructions.
+typedef const __attribute__((address_space(4))) StripItem *const_item_ptr;
+typedef const __attribute__((address_space(4))) StartDesc *const_start_ptr;
+struct QueueEntry { int s, unit, planes, pad; };        // (an int4 as the planner writes it)
+typedef const __attribute__((address_space(4))) QueueEntry *const_entry_ptr;
 
-__device__ __forceinline__ ColRegs load_col(const StripCol *__restrict__ cols, int ci)
+// What is needed of an item before its window can be read.
+struct ItemHdr { int rowoff; unsigned m0, m1; };
+__device__ __forceinline__ ItemHdr load_hdr(const StripItem *items, int i)
 {
-    ColRegs r;
-    const StripCol &c = cols[ci];
-    r.rowoff = c.rowoff;
-    r.mask = c.mask;
-    r.chunks = c.chunks;
-#pragma unroll
-    for (int t = 0; t < 16; t++) r.h[t] = c.h[t];
-    return r;
-}
-
-// Forces the whole descriptor to be resident in SGPRs here (one wait for all the
-// scalar loads instead of one load + wait in front of every offset).
-__device__ __forceinline__ void pin_col(ColRegs &r)
-{
-    asm volatile("; column descriptor resident"
-                 : "+s"(r.rowoff), "+s"(r.mask), "+s"(r.chunks), "+s"(r.h[1]), "+s"(r.h[2]),
-                   "+s"(r.h[3]), "+s"(r.h[4]), "+s"(r.h[5]), "+s"(r.h[6]), "+s"(r.h[7]),
-                   "+s"(r.h[8]), "+s"(r.h[9]), "+s"(r.h[10]), "+s"(r.h[11]), "+s"(r.h[12]),
-                   "+s"(r.h[13]), "+s"(r.h[14]), "+s"(r.h[15]));
+    const const_item_ptr it = (const_item_ptr)(items + i);
+    return ItemHdr{it->rowoff, it->mask[0], it->mask[1]};
 }
 
 // Activity flag word of a unit (tile_flags): where something improved, as seen by the
@@ -409,13 +397,11 @@ __device__ __forceinline__ void pin_col(ColRegs &r)
 enum : int { ZONE_ANY = 0, ZONE_LO = 1, ZONE_HI = 2, FLAG_ALL = 0x1ff };
 __host__ __device__ constexpr int flag_bit(int zone_b, int zone_c) { return 1 << (3 * zone_b + zone_c); }
 
-// Relax all offsets dc of one (da, db) column: load the neighbour window from LDS into
-// registers once, then fold every present offset into acc.  row: start of the lane's slab
-// row of v, swb: that row's swizzle in bytes (float4 j of the row is stored at byte
-// (16 j) ^ swb).
+// Relax the offsets `mask` (bit t <-> dc = t - 8) of one item into acc: window element w of
+// the neighbour row is pair w/2, half w&1 of vN2 / tN2 (registers).
 //
-// MASK != 0: the column's dc set is a compile-time constant -> straight-line code.
-// MASK == 0: runtime set (cur.mask), one scalar-branch-selected block per offset.
+// MASK != 0: the offset set is a compile-time constant -> straight-line code.
+// MASK == 0: runtime set (`mask`), one scalar-branch-selected block per offset.
 //
 // Arithmetic is packed (v_pk_add_f32 / v_pk_mul_f32, two cells per instruction; each
 // component rounds exactly like the scalar op).  Cell q needs window element q + t; the
@@ -423,78 +409,18 @@ __host__ __device__ constexpr int flag_bit(int zone_b, int zone_c) { return 1 <<
 // pair: even t -> cells (0,1),(2,3)..; odd t -> cells (1,2),(3,4).., with cells 0 and
 // K-1 done singly.  Measured (tools/microbench/relax_static.hip): straight-line packed
 // blocks sustain ~15 T relaxations/s against ~11 T/s for any scalar form.
-#ifdef TTSWEEP_PROFILE2
-#define g_p2 p2_local
-#define P2_PARAM , long long (&p2_local)[4]
-#define P2_ARG , p2
-#else
-#define P2_PARAM
-#define P2_ARG
-#endif
 template <int K, unsigned MASK>
-__device__ __forceinline__ void relax_column(const ColRegs &cur, const char *row, unsigned swb,
+__device__ __forceinline__ void relax_window(unsigned rt_mask, const float (&h)[16],
+                                             const f32x2 (&vN2)[(K + 2 * STRIP_CF) / 2],
+                                             const f32x2 (&tN2)[(K + 2 * STRIP_CF) / 2],
                                              const f32x2 (&vce)[K / 2], const f32x2 (&vco)[K / 2 - 1],
-                                             float (&acc)[K] P2_PARAM)
+                                             float (&acc)[K])
 {
-    constexpr int W = K + 2 * STRIP_CF;
-    constexpr bool STATIC = MASK != 0u;
-    const unsigned mask = STATIC ? MASK : cur.mask;
-    // window chunks (float4) that the present offsets read: elements t .. t+K-1
-    unsigned chunks = cur.chunks;
-    if (STATIC) {
-        chunks = 0;
-#pragma unroll
-        for (int t = 1; t < 2 * STRIP_CF; t++)
-            if (MASK & (1u << t))
-#pragma unroll
-                for (int j = 0; j < W / 4; j++)
-                    if (4 * j + 3 >= t && 4 * j <= t + K - 1) chunks |= 1u << j;
-    }
-#ifdef TTSWEEP_PROFILE2
-    const long long pc0 = clock64();
-#endif
-    f32x2 vN2[W / 2], tN2[W / 2];       // window element w is pair w/2, half w&1
-    static_assert(W / 4 == 8, "the window is 8 float4 wide");
-    f32x4 xw[W / 4], yw[W / 4];
-#pragma unroll
-    for (int j = 0; j < W / 4; j++) {
-        if (chunks & (1u << j)) {
-            // slab rows are XOR-swizzled (stage_slab); one v_xad_u32 per float4 pair, the T
-            // row sits at a compile-time distance behind the v row
-            const char *at = row + (swb ^ (unsigned)(16 * j));
-            xw[j] = *reinterpret_cast<const f32x4 *>(at);
-            yw[j] = *reinterpret_cast<const f32x4 *>(at + SLAB_T_BYTES);
-        }
-    }
-    // (chunks that are not read stand in for a loaded one below: no instructions)
-    constexpr int JF = STATIC ? __builtin_ctz(MASK) / 4 : 0;      // a chunk every column reads
-#pragma unroll
-    for (int j = 0; j < W / 4; j++) {
-        if (!(chunks & (1u << j))) {
-            if (STATIC) { xw[j] = xw[JF]; yw[j] = yw[JF]; }
-            else { xw[j] = f32x4{0.f, 0.f, 0.f, 0.f}; yw[j] = xw[j]; }
-        }
-    }
-    // All loads are issued before the first value is used, and whole float4s are kept: when
-    // a chunk is only partly used the compiler narrows the load and pairs the pieces into
-    // ds_read2_b64 (8 LDS cycles instead of 4).
-    asm volatile("" :: "v"(xw[0]), "v"(xw[1]), "v"(xw[2]), "v"(xw[3]), "v"(xw[4]), "v"(xw[5]),
-                 "v"(xw[6]), "v"(xw[7]), "v"(yw[0]), "v"(yw[1]), "v"(yw[2]), "v"(yw[3]), "v"(yw[4]),
-                 "v"(yw[5]), "v"(yw[6]), "v"(yw[7]));
-#pragma unroll
-    for (int j = 0; j < W / 4; j++) {
-        vN2[2 * j] = f32x2{xw[j].x, xw[j].y}; vN2[2 * j + 1] = f32x2{xw[j].z, xw[j].w};
-        tN2[2 * j] = f32x2{yw[j].x, yw[j].y}; tN2[2 * j + 1] = f32x2{yw[j].z, yw[j].w};
-    }
-#ifdef TTSWEEP_PROFILE2
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    const long long pc1 = clock64();
-    g_p2[0] += pc1 - pc0;
-#endif
+    const unsigned mask = MASK != 0u ? MASK : rt_mask;
 #pragma unroll
     for (int t = 1; t < 2 * STRIP_CF; t++) {
         if (mask & (1u << t)) {
-            const float hv = cur.h[t];
+            const float hv = h[t];
             const f32x2 h2 = {hv, hv};
             if ((t & 1) == 0) {
                 f32x2 x[K / 2];
@@ -535,10 +461,23 @@ __device__ __forceinline__ void relax_column(const ColRegs &cur, const char *row
             }
         }
     }
-#ifdef TTSWEEP_PROFILE2
-    asm volatile("" :: "v"(acc[0]), "v"(acc[K - 1]));
-    g_p2[1] += clock64() - pc1;
-#endif
+}
+
+// The straight-line routine of the item's offset set, or the generic one.
+template <int K>
+__device__ __forceinline__ void relax_dispatch(unsigned mask, const float (&h)[16],
+                                               const f32x2 (&vN2)[(K + 2 * STRIP_CF) / 2],
+                                               const f32x2 (&tN2)[(K + 2 * STRIP_CF) / 2],
+                                               const f32x2 (&vce)[K / 2], const f32x2 (&vco)[K / 2 - 1],
+                                               float (&acc)[K])
+{
+    switch (mask) {
+    case 0u: break;
+#define STRIP_MASK_CASE(m) case m: relax_window<K, m>(mask, h, vN2, tN2, vce, vco, acc); break;
+#include "strip_masks.inc"
+#undef STRIP_MASK_CASE
+    default: relax_window<K, 0u>(mask, h, vN2, tN2, vce, vco, acc); break;
+    }
 }
 
 __global__ void __launch_bounds__(256)
@@ -561,14 +500,17 @@ init_tile_flags_box_kernel(DevLayout L, const float *__restrict__ T, int *__rest
     int u = blockIdx.x;
     const int cs = u % cstrips;  u /= cstrips;
     const int bt = u % btiles;   u /= btiles;
-    const int a = u;
+    const int A = u;
     const int lane = threadIdx.x;
-    const long long g = (long long)(a + L.lo[0]) * L.s0
-                      + (long long)(bt * STRIP_TB + lane + L.lo[1]) * L.s1 + (cs * STRIP_K + L.lo[2]);
     bool finite = false;
-    if (bt * STRIP_TB + lane < L.n[1])
+    for (int j = 0; j < STRIP_PLANES; j++) {
+        const int a = STRIP_PLANES * A + j;
+        if (a >= L.n[0] || bt * STRIP_TB + lane >= L.n[1]) continue;
+        const long long g = (long long)(a + L.lo[0]) * L.s0
+                          + (long long)(bt * STRIP_TB + lane + L.lo[1]) * L.s1 + (cs * STRIP_K + L.lo[2]);
 #pragma unroll
         for (int q = 0; q < STRIP_K; q++) finite |= T[g + q] < __builtin_inff();
+    }
     const bool any = __ballot(finite) != 0ull;
     if (lane == 0) {
         flags[blockIdx.x] = 0;
@@ -590,7 +532,7 @@ hipError_t launch_init_tile_flags(const DevLayout &L, const StartDesc &sd, bool 
                            sd.tile_flags, nunits, btiles, cstrips);
         return hipGetLastError();
     }
-    const int start_unit = (sd.sa * btiles + sd.sb / STRIP_TB) * cstrips + sd.sc / STRIP_K;
+    const int start_unit = ((sd.sa / STRIP_PLANES) * btiles + sd.sb / STRIP_TB) * cstrips + sd.sc / STRIP_K;
     hipLaunchKernelGGL(init_tile_flags_kernel, dim3((nunits + 255) / 256), dim3(256), 0, st,
                        sd.tile_flags, nunits, start_unit);
     return hipGetLastError();
@@ -600,11 +542,12 @@ hipError_t launch_init_tile_flags(const DevLayout &L, const StartDesc &sd, bool 
 // a pass: unit queues drained by a persistent grid
 // ---------------------------------------------------------------------------
 //
-// Activity tracking.  A unit's offsets with plane offset da have to be relaxed in a pass
-// only if a unit they read from (plane a+da, +-1 lane tile, +-1 strip) improved in the
-// previous pass: everything else was already relaxed against unchanged values.  Every
-// unit has a flag word per pass parity (where it improved, by border zone: see flag_bit), so
-// that a neighbouring strip or lane tile reacts only to improvements within its reach.
+// Activity tracking.  A unit's offsets against staged plane q have to be relaxed in a pass
+// only if a unit they read from (the plane pair holding q, +-1 lane tile, +-1 strip)
+// improved in the previous pass: everything else was already relaxed against unchanged
+// values.  Every unit has a flag word per pass parity (where it improved, by border zone:
+// see flag_bit), so that a neighbouring strip or lane tile reacts only to improvements
+// within its reach.
 //
 // Distance gate.  Far from the start the first values to arrive (over long edges) are
 // poor and get refined pass after pass; relaxing those units early is wasted work.  A unit
@@ -616,12 +559,12 @@ hipError_t launch_init_tile_flags(const DevLayout &L, const StartDesc &sd, bool 
 // relaxed ungated.
 //
 // Only a shell of units is due in any pass, and most workgroups of a grid-per-unit launch
-// would start, read their neighbours' flags and leave.  A pass therefore runs in two steps: plan_pass_kernel (one THREAD per unit) decides which units
-// are due and writes them, in work-list order, into one queue per XCD; sweep_units_kernel,
-// a grid of two workgroups per CU, drains the queues (own XCD's
-// first, then the others').  A workgroup relaxes ONE unit at a time, its four waves
-// splitting the star's columns among themselves (nearly equal shares, StripPlan::wsplit)
-// and min-combining their partial results through LDS.
+// would start, read their neighbours' flags and leave.  A pass therefore runs in two steps:
+// plan_pass_kernel (one THREAD per unit) decides which units are due and writes them, in
+// work-list order, into one queue per XCD; sweep_units_kernel, a grid of two workgroups per
+// CU, drains the queues (own XCD's first, then the others').  A workgroup relaxes ONE unit
+// at a time, its four waves splitting the items of every staged plane among themselves
+// (nearly equal shares, StripPlan::wsplit) and min-combining their partial results through LDS.
 
 __global__ void __launch_bounds__(256)
 plan_pass_kernel(DevLayout L, const StartDesc *__restrict__ starts, const int2 *__restrict__ work,
@@ -645,15 +588,16 @@ plan_pass_kernel(DevLayout L, const StartDesc *__restrict__ starts, const int2 *
     }
     if (unit >= 0) {
         const StartDesc sd = starts[s];
-        const int nunits = L.n[0] * btiles * cstrips;
+        const int nunits = strip_apairs(L) * btiles * cstrips;
         int u = unit;
         const int cs = u % cstrips;  u /= cstrips;
         const int bt = u % btiles;   u /= btiles;
-        const int a = u;
+        const int a0 = STRIP_PLANES * u;        // first own plane
         const int *__restrict__ prev_flags = sd.tile_flags + (1 - parity) * nunits;
-        for (int ia = 0; ia <= 2 * ra; ia++) {
-            const int na = a + ia - ra;
-            if (na < 0 || na >= L.n[0]) continue;
+        for (int p = 0; p < 2 * ra + STRIP_PLANES; p++) {
+            const int q = a0 - ra + p;          // staged plane
+            if (q < 0 || q >= L.n[0]) continue;
+            const int qa = q / STRIP_PLANES;    // the unit row that owns it
             bool due = false;
             for (int r = 0; r < 9; r++) {
                 const int nb = bt + r / 3 - 1, nc = cs + r % 3 - 1;
@@ -661,16 +605,16 @@ plan_pass_kernel(DevLayout L, const StartDesc *__restrict__ starts, const int2 *
                 const int need = flag_bit(r / 3 == 0 ? ZONE_HI : r / 3 == 2 ? ZONE_LO : ZONE_ANY,
                                           r % 3 == 0 ? ZONE_HI : r % 3 == 2 ? ZONE_LO : ZONE_ANY);
                 if (nb >= 0 && nb < btiles && nc >= 0 && nc < cstrips
-                    && (prev_flags[(na * btiles + nb) * cstrips + nc] & need))
+                    && (prev_flags[(qa * btiles + nb) * cstrips + nc] & need))
                     due = true;
             }
-            if (due) planes |= 1u << ia;
+            if (due) planes |= 1u << p;
         }
         // distance gate and held-back plane bits
         unsigned *__restrict__ pend = reinterpret_cast<unsigned *>(sd.tile_flags + 2 * nunits);
         const int b0 = bt * STRIP_TB, cb0 = cs * STRIP_K;
         const int tb_eff = min(STRIP_TB, L.n[1]);
-        const float da_ = (float)abs(a - sd.sa);
+        const float da_ = (float)max(max(a0 - sd.sa, sd.sa - (a0 + STRIP_PLANES - 1)), 0);
         const float db_ = (float)max(max(b0 - sd.sb, sd.sb - (b0 + tb_eff - 1)), 0);
         const float dc_ = (float)max(max(cb0 - sd.sc, sd.sc - (cb0 + STRIP_K - 1)), 0);
         const bool gated = sd.tile_flags[3 * nunits] == 1;
@@ -740,7 +684,8 @@ __device__ __forceinline__ void relax_special_cell(const DevLayout &L, const flo
         T[ci] = best;
         atomicOr(&changed[s], CHANGED_IMPROVED);
         const int btiles = strip_btiles(L), cstrips = strip_cstrips(L);
-        atomicOr(sd.tile_flags + parity * strip_units(L) + (a * btiles + b / STRIP_TB) * cstrips + c / STRIP_K, FLAG_ALL);
+        atomicOr(sd.tile_flags + parity * strip_units(L)
+                 + ((a / STRIP_PLANES) * btiles + b / STRIP_TB) * cstrips + c / STRIP_K, FLAG_ALL);
     }
 }
 
@@ -750,7 +695,7 @@ __device__ __forceinline__ void relax_special_cell(const DevLayout &L, const flo
 // l % 8 of row l / 8), so the rows cannot be padded against bank conflicts; instead float4 j
 // of row r is stored at position j ^ ((r >> 1) & 7): 16 consecutive lanes reading the same
 // float4 of 16 consecutive rows then hit all 64 banks (the swizzle is applied to the SOURCE
-// address here and to the read address in relax_column).
+// address here and to the read address in the window load).
 __device__ __forceinline__ int slab_swizzle(int row) { return (row >> 1) & 7; }
 
 //
@@ -797,7 +742,6 @@ __device__ __forceinline__ void stage_slab(const float *__restrict__ v_slab, con
 // -DTTSWEEP_PROFILE: cycle counts of wave 0 per phase, summed over all units (tuning aid)
 #ifdef TTSWEEP_PROFILE
 __device__ unsigned long long g_prof[8];
-__device__ unsigned long long g_prof2[4];
 #define PROF_T(x) const long long x = clock64()
 void prof_dump()
 {
@@ -808,13 +752,8 @@ void prof_dump()
             "compute %.0f  epilogue %.0f  | busy / resident cycles of the workgroups: %.3f\n",
             h[6], h[0] / n, h[1] / n, h[2] / n, h[3] / n, h[4] / n, h[5] / n,
             (double)(h[0] + h[1] + h[2] + h[3] + h[4] + h[5]) / (double)std::max<unsigned long long>(h[7], 1));
-    unsigned long long h2[4] = {};
-    (void)hipMemcpyFromSymbol(h2, HIP_SYMBOL(g_prof2), sizeof(h2));
-    fprintf(stderr, "prof2 (wave 0, cycles per unit): %.1f columns: whole column loop %.0f, of it window load + wait %.0f, "
-            "arithmetic %.0f\n", h2[3] / n, h2[2] / n, h2[0] / n, h2[1] / n);
     unsigned long long z[8] = {};
     (void)hipMemcpyToSymbol(HIP_SYMBOL(g_prof), z, sizeof(z));
-    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_prof2), z, sizeof(h2));
 }
 #else
 #define PROF_T(x)
@@ -832,11 +771,14 @@ template <int K>
 __global__ void __launch_bounds__(STRIP_TB *STRIP_NS, TTSWEEP_WGS_PER_CU)
 sweep_units_kernel(DevLayout L, const float *__restrict__ v, const StartDesc *__restrict__ starts,
                    const int4 *__restrict__ lists, int list_cap, int nlists, int *__restrict__ ctrl,
-                   int *__restrict__ changed, const StripCol *__restrict__ cols, StripPlan plan,
+                   int *__restrict__ changed, const StripItem *__restrict__ items, StripPlan plan,
                    int btiles, int cstrips, int parity, UnitPassTail tail)
 {
     constexpr int NS = STRIP_NS;
-    static_assert(K == STRIP_K && STRIP_W == 32, "slab rows are 8 float4 wide");
+    constexpr int NP = STRIP_PLANES;
+    constexpr int W = K + 2 * STRIP_CF;
+    static_assert(K == STRIP_K && STRIP_W == 32 && W == 32, "slab rows are 8 float4 wide");
+    static_assert(NP == 2 && NS == 4, "two own planes, four waves: wave w finishes half a row of plane w / 2");
     extern __shared__ __attribute__((aligned(16))) float smem[];
     int *head = reinterpret_cast<int *>(smem);      // [0], [1]: queue index handed to the workgroup
 
@@ -849,25 +791,25 @@ sweep_units_kernel(DevLayout L, const float *__restrict__ v, const StartDesc *__
     const int lane_r = min(lane, tb_eff - 1);
     const int rows8 = (rows + 7) & ~7;
     constexpr int slab_floats = SLAB_BYTES / 4;     // v rows, then T rows
-    const int nunits = L.n[0] * btiles * cstrips;
+    const int nunits = strip_apairs(L) * btiles * cstrips;
     float *slabs = smem + STRIP_LDS_HEAD;           // two slabs (double buffer)
-    float *comb = smem + STRIP_LDS_HEAD;            // [wave][cell][lane], aliases the slabs
-    const int ncols = plan.first[2 * plan.ra + 1];
-    unsigned plane_mask = 0;                        // plane offsets that have columns at all
-    for (int ia = 0; ia <= 2 * plan.ra; ia++)
-        if (plan.first[ia] != plan.first[ia + 1]) plane_mask |= 1u << ia;
-    // column range [lo, hi) of wave w for plane offset ia, packed lo | hi << 16, in LDS: read
+    float *comb = smem + STRIP_LDS_HEAD;            // [wave][plane][cell][lane], aliases the slabs
+    const int nitems = plan.first[plan.nstaged];
+    unsigned plane_mask = 0;                        // staged planes that have items at all
+    for (int p = 0; p < plan.nstaged; p++)
+        if (plan.first[p] != plan.first[p + 1]) plane_mask |= 1u << p;
+    // item range [lo, hi) of wave w for staged plane p, packed lo | hi << 16, in LDS: read
     // once per plane with LDS latency instead of a chain of scalar memory loads
-    int *col_range = reinterpret_cast<int *>(smem) + 16;
+    int *item_range = reinterpret_cast<int *>(smem) + 16;
     if (tid < NS * 16) {
-        const int w = tid >> 4, ia = tid & 15;
+        const int w = tid >> 4, p = tid & 15;
         int packed = 0;
-        if (ia <= 2 * plan.ra)
-            packed = (plan.first[ia] + plan.wsplit[ia][w]) | ((plan.first[ia] + plan.wsplit[ia][w + 1]) << 16);
-        col_range[tid] = packed;
+        if (p < plan.nstaged)
+            packed = (plan.first[p] + plan.wsplit[p][w]) | ((plan.first[p] + plan.wsplit[p][w + 1]) << 16);
+        item_range[tid] = packed;
     }
-    int *plane_nent = col_range + NS * 16;          // offsets per plane offset (statistics)
-    if (tid < 16) plane_nent[tid] = tid <= 2 * plan.ra ? plan.nent[tid] : 0;
+    int *plane_nent = item_range + NS * 16;         // offsets per staged plane and own plane (statistics)
+    if (tid < 32) plane_nent[tid] = (tid >> 1) < plan.nstaged ? plan.nent[tid >> 1][tid & 1] : 0;
     __syncthreads();
 
     // ---- the dead-edge cells of the active starts, one wave per cell
@@ -883,51 +825,63 @@ sweep_units_kernel(DevLayout L, const float *__restrict__ v, const StartDesc *__
     // volumes then stay in one L2; any workgroup may drain any queue)
     const int home = (int)(xcc_id() % (unsigned)nlists);
     int probe = 0, it = 0;
+    // The index of the unit after the current one is asked for while the current one is being
+    // relaxed (`ahead`, held by thread 0); -1: nothing asked for yet.
+    int ahead = -1;
     while (probe < nlists) {
         // ---- take the next unit of queue q (every wave leaves through the same exit:
         // all queues exhausted)
         PROF_T(t_top);
         const int q = (home + probe) % nlists;
         const int n = ctrl[q];
-        if (tid == 0) head[it & 1] = ctrl[UNITQ_LISTS + q] < n ? atomicAdd(&ctrl[UNITQ_LISTS + q], 1) : n;
+        if (tid == 0) {
+            int j = ahead;
+            if (j < 0) j = ctrl[UNITQ_LISTS + q] < n ? atomicAdd(&ctrl[UNITQ_LISTS + q], 1) : n;
+            head[it & 1] = j;
+        }
         __syncthreads();
         const int j = __builtin_amdgcn_readfirstlane(head[it & 1]);
         it++;
+        ahead = -1;
         if (j >= n) { probe++; continue; }
+        if (tid == 0) ahead = atomicAdd(&ctrl[UNITQ_LISTS + q], 1);     // (arrives during the unit)
         PROF_T(t_fetch);
 #ifdef TTSWEEP_PROFILE
         long long p_wait = 0, p_stage = 0, p_comp = 0;
 #endif
-#ifdef TTSWEEP_PROFILE2
-        long long p2[4] = {0, 0, 0, 0};
-#endif
-        const int4 item = lists[(size_t)q * list_cap + j];
-        const int s = __builtin_amdgcn_readfirstlane(item.x);
-        const int my_unit = __builtin_amdgcn_readfirstlane(item.y);
-        const unsigned my_planes = (unsigned)__builtin_amdgcn_readfirstlane(item.z);
+        const const_entry_ptr entry = (const_entry_ptr)(lists + ((size_t)q * list_cap + j));
+        const int s = entry->s;
+        const int my_unit = entry->unit;
+        const unsigned my_planes = (unsigned)entry->planes;
         int u = my_unit;
         const int cs = u % cstrips;  u /= cstrips;
         const int bt = u % btiles;   u /= btiles;
-        const int a = u;
+        const int a0 = NP * u;                      // first own plane
         const int b0 = bt * STRIP_TB;
         const int c0 = cs * K;
 
-        const StartDesc sd = starts[s];
-        float *__restrict__ T = sd.T;
+        const const_start_ptr sdp = (const_start_ptr)(starts + s);
+        float *const T = sdp->T;
+        int *const tile_flags = sdp->tile_flags;
+        unsigned long long *const work = sdp->work;
+        const int box_lo0 = sdp->box_lo[0], box_lo1 = sdp->box_lo[1], box_lo2 = sdp->box_lo[2];
+        const int box_hi0 = sdp->box_hi[0], box_hi1 = sdp->box_hi[1], box_hi2 = sdp->box_hi[2];
+        const int nplanes = min(NP, L.n[0] - a0);   // own planes inside the grid
         if (tid == 0) {     // statistics: cells x offsets relaxed, units
             const int wb = min(tb_eff, L.n[1] - b0), wc = max(min(K, L.n[2] - c0), 0);
             int nent = 0;
 #pragma unroll
-            for (int ia = 0; ia < 16; ia++)
-                if ((my_planes >> ia) & 1u) nent += plane_nent[ia];
-            atomicAdd(sd.work, (unsigned long long)(wb * wc) * (unsigned long long)nent);
-            atomicAdd(sd.work + 2, 1ull);
+            for (int p = 0; p < 16; p++)
+                if ((my_planes >> p) & 1u) nent += plane_nent[2 * p] + (nplanes > 1 ? plane_nent[2 * p + 1] : 0);
+            atomicAdd(work, (unsigned long long)(wb * wc) * (unsigned long long)nent);
+            atomicAdd(work + 2, 1ull);
         }
 
-        // ---- planes to relax, in order; the first one starts to load right away.  Slab of
-        // plane a+da: rows b0-rb .. b0+63+rb, columns c0-CF .. c0+K+CF-1.
+        // ---- staged planes to relax against, in order; the first one starts to load right
+        // away.  Slab of staged plane p (plane a0 - ra + p): rows b0-rb .. b0+63+rb, columns
+        // c0-CF .. c0+K+CF-1.
         unsigned todo = my_planes & plane_mask;
-        const long long src0 = (long long)(a - plan.ra + L.lo[0]) * L.s0
+        const long long src0 = (long long)(a0 - plan.ra + L.lo[0]) * L.s0
                              + (long long)(b0 - rb + L.lo[1]) * L.s1 + (c0 - STRIP_CF + L.lo[2]);
         const unsigned s1_bytes = (unsigned)(L.s1 * 4);
         int buf = 0;
@@ -935,40 +889,55 @@ sweep_units_kernel(DevLayout L, const float *__restrict__ v, const StartDesc *__
             const long long src = src0 + (long long)__builtin_ctz(todo) * L.s0;
             stage_slab(v + src, T + src, s1_bytes, slabs, rows, rows8, wave, lane);
         }
-        // descriptor of the first column this wave will relax (later ones are requested one
-        // column ahead, across plane boundaries)
-        ColRegs cur = load_col(cols, min(__builtin_amdgcn_readfirstlane(col_range[wave * 16 + (todo ? __builtin_ctz(todo) : 0)]) & 0xffff,
-                                         ncols - 1));
+        // header of the first item this wave will relax (later ones are requested one item
+        // ahead, across plane boundaries)
+        ItemHdr cur = load_hdr(items, min(__builtin_amdgcn_readfirstlane(
+            item_range[wave * 16 + (todo ? __builtin_ctz(todo) : 0)]) & 0xffff, nitems - 1));
 
-        // own cells: (a, b0 + lane, c0 + q)
-        const long long own = (long long)(a + L.lo[0]) * L.s0 + (long long)(b0 + lane_r + L.lo[1]) * L.s1
+        // own cells: (a0 + j, b0 + lane, c0 + q)
+        const long long own = (long long)(a0 + L.lo[0]) * L.s0 + (long long)(b0 + lane_r + L.lo[1]) * L.s1
                             + (c0 + L.lo[2]);
-        float acc[K];
-        f32x2 vce[K / 2];
-        f32x2 vco[K / 2 - 1];
+        float acc[NP][K];
+        f32x2 vce[NP][K / 2];
+        f32x2 vco[NP][K / 2 - 1];
 #pragma unroll
-        for (int jj = 0; jj < K / 4; jj++) {
-            const float4 xx = *reinterpret_cast<const float4 *>(v + own + 4 * jj);
-            const float4 yy = *reinterpret_cast<const float4 *>(T + own + 4 * jj);
-            vce[2 * jj] = f32x2{xx.x, xx.y}; vce[2 * jj + 1] = f32x2{xx.z, xx.w};
-            acc[4 * jj + 0] = yy.x; acc[4 * jj + 1] = yy.y; acc[4 * jj + 2] = yy.z; acc[4 * jj + 3] = yy.w;
+        for (int jp = 0; jp < NP; jp++) {
+#pragma unroll
+            for (int jj = 0; jj < K / 4; jj++) {
+                const float4 xx = *reinterpret_cast<const float4 *>(v + own + jp * L.s0 + 4 * jj);
+                const float4 yy = *reinterpret_cast<const float4 *>(T + own + jp * L.s0 + 4 * jj);
+                vce[jp][2 * jj] = f32x2{xx.x, xx.y}; vce[jp][2 * jj + 1] = f32x2{xx.z, xx.w};
+                acc[jp][4 * jj + 0] = yy.x; acc[jp][4 * jj + 1] = yy.y;
+                acc[jp][4 * jj + 2] = yy.z; acc[jp][4 * jj + 3] = yy.w;
+            }
+#pragma unroll
+            for (int p = 0; p < K / 2 - 1; p++) vco[jp][p] = f32x2{vce[jp][p].y, vce[jp][p + 1].x};
         }
+        // what this wave will finish and store at the end: cells 8 (wave & 1) .. + 7 of own
+        // plane wave / 2; their values before this unit's relaxation stay in registers
+        constexpr int CQ = NP * K / NS;     // cells per wave in the epilogue
+        static_assert(CQ * 2 == K, "a wave finishes half a row of one own plane");
+        const int fin_plane = wave >> 1, fin_q0 = (wave & 1) * CQ;
+        float told[CQ];
 #pragma unroll
-        for (int p = 0; p < K / 2 - 1; p++) vco[p] = f32x2{vce[p].y, vce[p + 1].x};
+        for (int qq = 0; qq < CQ; qq++) {
+            const float lo = fin_plane ? acc[1][qq] : acc[0][qq];
+            const float hi = fin_plane ? acc[1][CQ + qq] : acc[0][CQ + qq];
+            told[qq] = (wave & 1) ? hi : lo;
+        }
 
         PROF_T(t_pro);
         while (todo) {
-            const int ia = __builtin_ctz(todo);
+            const int p = __builtin_ctz(todo);
             todo &= todo - 1;
             PROF_T(t0);
-            // this wave's share of the plane offset's columns, and where it continues in the
-            // next plane
-            const int range = __builtin_amdgcn_readfirstlane(col_range[wave * 16 + ia]);
-            const int cbeg = range & 0xffff, cend = range >> 16;
+            // this wave's share of the staged plane's items, and where it continues in the next
+            const int range = __builtin_amdgcn_readfirstlane(item_range[wave * 16 + p]);
+            const int ibeg = range & 0xffff, iend = range >> 16;
             const int next_first = todo
-                ? min(__builtin_amdgcn_readfirstlane(col_range[wave * 16 + __builtin_ctz(todo)]) & 0xffff, ncols - 1)
+                ? min(__builtin_amdgcn_readfirstlane(item_range[wave * 16 + __builtin_ctz(todo)]) & 0xffff, nitems - 1)
                 : 0;
-            // this wave's part of slab `ia` has landed ...
+            // this wave's part of slab `p` has landed ...
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             // ... and so has everybody else's; the other slab is no longer read
             __syncthreads();
@@ -984,27 +953,46 @@ sweep_units_kernel(DevLayout L, const float *__restrict__ v, const StartDesc *__
 #endif
 
             const float *sv = slabs + buf * slab_floats;
-            for (int ci = cbeg; ci < cend; ci++) {
-#ifdef TTSWEEP_PROFILE2
-                const long long tc0 = clock64();
-#endif
-                pin_col(cur);
-                const ColRegs nxt = load_col(cols, ci + 1 < cend ? ci + 1 : next_first);
-                const int row = lane_r + rb + cur.rowoff;
+            for (int ii = ibeg; ii < iend; ii++) {
+                const const_item_ptr item = (const_item_ptr)(items + ii);
+                // this item's offset lengths and the next item's header travel while the
+                // window is being read
+                const ItemHdr nxt = load_hdr(items, ii + 1 < iend ? ii + 1 : next_first);
+                float h0[16], h1[16];
+#pragma unroll
+                for (int t = 1; t < 16; t++) { h0[t] = item->h[0][t]; h1[t] = item->h[1][t]; }
+                const int rowoff = cur.rowoff;
+                const unsigned m0 = cur.m0, m1 = cur.m1;
+                // the neighbour window of this item's slab row, both arrays, into registers:
+                // slab rows are XOR-swizzled (stage_slab); one v_xad_u32 per float4 pair, the T
+                // row sits at a compile-time distance behind the v row
+                const int row = lane_r + rb + rowoff;
                 const char *prow = reinterpret_cast<const char *>(sv) + row * (STRIP_W * 4);
                 const unsigned swb = (unsigned)slab_swizzle(row) << 4;
-                switch (cur.mask) {
-#define STRIP_MASK_CASE(m) case m: relax_column<K, m>(cur, prow, swb, vce, vco, acc P2_ARG); break;
-#include "strip_masks.inc"
-#undef STRIP_MASK_CASE
-                default: relax_column<K, 0u>(cur, prow, swb, vce, vco, acc P2_ARG); break;
+                f32x4 xw[W / 4], yw[W / 4];
+#pragma unroll
+                for (int jj = 0; jj < W / 4; jj++) {
+                    const char *at = prow + (swb ^ (unsigned)(16 * jj));
+                    xw[jj] = *reinterpret_cast<const f32x4 *>(at);
+                    yw[jj] = *reinterpret_cast<const f32x4 *>(at + SLAB_T_BYTES);
                 }
-#ifdef TTSWEEP_PROFILE2
-                p2[2] += clock64() - tc0; p2[3] += 1;
-#endif
+                // All loads are issued before the first value is used, and whole float4s are
+                // kept: partly used chunks would otherwise be narrowed to ds_read2_b64 pairs
+                // (8 LDS cycles instead of 4).
+                asm volatile("" :: "v"(xw[0]), "v"(xw[1]), "v"(xw[2]), "v"(xw[3]), "v"(xw[4]), "v"(xw[5]),
+                             "v"(xw[6]), "v"(xw[7]), "v"(yw[0]), "v"(yw[1]), "v"(yw[2]), "v"(yw[3]), "v"(yw[4]),
+                             "v"(yw[5]), "v"(yw[6]), "v"(yw[7]));
+                f32x2 vN2[W / 2], tN2[W / 2];       // window element w is pair w/2, half w&1
+#pragma unroll
+                for (int jj = 0; jj < W / 4; jj++) {
+                    vN2[2 * jj] = f32x2{xw[jj].x, xw[jj].y}; vN2[2 * jj + 1] = f32x2{xw[jj].z, xw[jj].w};
+                    tN2[2 * jj] = f32x2{yw[jj].x, yw[jj].y}; tN2[2 * jj + 1] = f32x2{yw[jj].z, yw[jj].w};
+                }
+                relax_dispatch<K>(m0, h0, vN2, tN2, vce[0], vco[0], acc[0]);
+                relax_dispatch<K>(m1, h1, vN2, tN2, vce[1], vco[1], acc[1]);
                 cur = nxt;
             }
-            if (cbeg >= cend) cur = load_col(cols, next_first);     // (no column of this plane was ours)
+            if (ibeg >= iend) cur = load_hdr(items, next_first);    // (no item of this plane was ours)
             buf ^= 1;
 #ifdef TTSWEEP_PROFILE
             p_comp += clock64() - t2;
@@ -1012,36 +1000,39 @@ sweep_units_kernel(DevLayout L, const float *__restrict__ v, const StartDesc *__
         }
         PROF_T(t_loop);
 
-        // ---- min-combine the waves' partial results; wave w finishes cells 4w .. 4w+3
+        // ---- min-combine the waves' partial results; wave w finishes cells fin_q0 .. + CQ - 1
+        // of own plane fin_plane
         __syncthreads();                // the last slab is no longer read
 #pragma unroll
-        for (int qq = 0; qq < K; qq++) comb[(wave * K + qq) * STRIP_TB + lane] = acc[qq];
+        for (int jp = 0; jp < NP; jp++)
+#pragma unroll
+            for (int qq = 0; qq < K; qq++) comb[((wave * NP + jp) * K + qq) * STRIP_TB + lane] = acc[jp][qq];
         __syncthreads();
-        constexpr int CQ = K / NS;      // cells per wave in the epilogue
-        const int q0 = wave * CQ;
         float best[CQ];
 #pragma unroll
         for (int qq = 0; qq < CQ; qq++) {
-            float m = comb[(0 * K + q0 + qq) * STRIP_TB + lane];
+            float m = comb[((0 * NP + fin_plane) * K + fin_q0 + qq) * STRIP_TB + lane];
 #pragma unroll
-            for (int w = 1; w < NS; w++) m = fminf(m, comb[(w * K + q0 + qq) * STRIP_TB + lane]);
+            for (int w = 1; w < NS; w++) m = fminf(m, comb[((w * NP + fin_plane) * K + fin_q0 + qq) * STRIP_TB + lane]);
             best[qq] = m;
         }
         // store improved cells that lie inside the grid and outside the dead-edge box
+        const int a = a0 + fin_plane;
         const int b = b0 + lane;
-        const bool row_ok = lane < tb_eff && b < L.n[1];
-        const bool in_box_ab = a >= sd.box_lo[0] && a <= sd.box_hi[0] && b >= sd.box_lo[1] && b <= sd.box_hi[1];
+        const bool row_ok = lane < tb_eff && b < L.n[1] && a < L.n[0];
+        const bool in_box_ab = a >= box_lo0 && a <= box_hi0 && b >= box_lo1 && b <= box_hi1;
         int improved = 0;
         // zones of this lane's row along b (3 bits: ANY, LO, HI), spread to the b positions
         // of the flag word: zone set Zc of a cell becomes Zc | Zc << 3 (LO) | Zc << 6 (HI)
         const int zb_lo = lane < rb, zb_hi = lane >= STRIP_TB - rb;
+        float *const Trow = T + own + fin_plane * L.s0 + fin_q0;
 #pragma unroll
         for (int qq = 0; qq < CQ; qq++) {
-            const int cq = q0 + qq;
+            const int cq = fin_q0 + qq;
             const int c = c0 + cq;
-            const bool special = in_box_ab && c >= sd.box_lo[2] && c <= sd.box_hi[2];
-            if (row_ok && c < L.n[2] && !special && best[qq] < T[own + cq]) {
-                T[own + cq] = best[qq];
+            const bool special = in_box_ab && c >= box_lo2 && c <= box_hi2;
+            if (row_ok && c < L.n[2] && !special && best[qq] < told[qq]) {
+                Trow[qq] = best[qq];
                 const int zc = 1 | (cq < STRIP_CF - 1 ? 2 : 0) | (cq > K - STRIP_CF ? 4 : 0);
                 improved |= zc | (zb_lo ? zc << 3 : 0) | (zb_hi ? zc << 6 : 0);
             }
@@ -1049,7 +1040,7 @@ sweep_units_kernel(DevLayout L, const float *__restrict__ v, const StartDesc *__
 #pragma unroll
         for (int w = 32; w >= 1; w >>= 1) improved |= __shfl_xor(improved, w);
         if (lane == 0 && improved) {
-            atomicOr(sd.tile_flags + parity * nunits + my_unit, improved);
+            atomicOr(tile_flags + parity * nunits + my_unit, improved);
             atomicOr(&changed[s], CHANGED_IMPROVED);
         }
 #ifdef TTSWEEP_PROFILE
@@ -1062,12 +1053,6 @@ sweep_units_kernel(DevLayout L, const float *__restrict__ v, const StartDesc *__
             atomicAdd(&g_prof[4], (unsigned long long)p_comp);
             atomicAdd(&g_prof[5], (unsigned long long)(t_end - t_loop));
             atomicAdd(&g_prof[6], 1ull);
-#ifdef TTSWEEP_PROFILE2
-            atomicAdd(&g_prof2[0], (unsigned long long)p2[0]);
-            atomicAdd(&g_prof2[1], (unsigned long long)p2[1]);
-            atomicAdd(&g_prof2[2], (unsigned long long)p2[2]);
-            atomicAdd(&g_prof2[3], (unsigned long long)p2[3]);
-#endif
         }
 #endif
     }
@@ -1098,7 +1083,7 @@ size_t units_lds_bytes(const StripPlan &plan, int nb)
 {
     (void)plan; (void)nb;
     size_t floats = (size_t)2 * SLAB_BYTES / 4;                             // two slabs of v and T rows
-    floats = std::max(floats, (size_t)STRIP_NS * STRIP_K * STRIP_TB);       // combine buffer
+    floats = std::max(floats, (size_t)STRIP_NS * STRIP_PLANES * STRIP_K * STRIP_TB);    // combine buffer
     return (floats + STRIP_LDS_HEAD) * sizeof(float);
 }
 
@@ -1122,7 +1107,7 @@ hipError_t launch_plan_pass(const DevLayout &L, const StartDesc *starts, const i
 
 hipError_t launch_sweep_units(const DevLayout &L, const float *v, const StartDesc *starts,
                               const int4 *lists, int list_cap, int nlists, int *ctrl, int nblocks,
-                              int *changed, const StripCol *cols, const StripPlan &plan,
+                              int *changed, const StripItem *items, const StripPlan &plan,
                               int parity, const UnitPassTail &tail, hipStream_t st)
 {
     if (nblocks <= 0 || nlists < 1 || nlists > UNITQ_LISTS)
@@ -1136,7 +1121,7 @@ hipError_t launch_sweep_units(const DevLayout &L, const float *v, const StartDes
         if (e != hipSuccess) return e;
     }
     hipLaunchKernelGGL(kern, dim3((unsigned)nblocks), dim3(STRIP_TB, STRIP_NS), lds, st, L, v, starts,
-                       lists, list_cap, nlists, ctrl, changed, cols, plan, btiles, strip_cstrips(L), parity, tail);
+                       lists, list_cap, nlists, ctrl, changed, items, plan, btiles, strip_cstrips(L), parity, tail);
     return hipGetLastError();
 }
 
