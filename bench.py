@@ -131,7 +131,8 @@ def reference_sweep_counts(star, starts):
 def workload_args(args):
     return ["--grid", args.grid, "--star", args.star, "--starts", args.starts,
             "--nstarts", str(args.nstarts), "--kernel", str(args.kernel)] + \
-        (["--gate-speed", str(args.gate_speed)] if args.gate_speed is not None else [])
+        (["--gate-speed", str(args.gate_speed)] if args.gate_speed is not None else []) + \
+        (["--pair-min-starts", str(args.pair_min_starts)] if args.pair_min_starts is not None else [])
 
 
 def measure_traffic(args, kernel_patterns):
@@ -223,6 +224,8 @@ def main():
     ap.add_argument("--nstarts", type=int, default=0, help="use only the first N start points")
     ap.add_argument("--kernel", type=int, default=0)
     ap.add_argument("--gate-speed", type=float, default=None, help="schedule knob of the STRIP kernel (cells/pass)")
+    ap.add_argument("--pair-min-starts", type=int, default=None,
+                    help="schedule knob of the STRIP kernel: units of two planes from this many starts on")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline legs")
     ap.add_argument("--no-traffic", action="store_true", help="skip the rocprofv3 --pmc child passes")
     ap.add_argument("--no-host", action="store_true", help="skip the host-program end-to-end leg")
@@ -292,6 +295,8 @@ def main():
         sol.set_option(P.OPT_KERNEL, args.kernel)
     if args.gate_speed is not None:
         sol.set_option(P.OPT_GATE_SPEED_MILLI, int(round(args.gate_speed * 1000)))
+    if args.pair_min_starts is not None:
+        sol.set_option(P.OPT_PAIR_MIN_STARTS, args.pair_min_starts)
     sol.set_velocity(v_dev)
     tt = torch.empty((len(mine), nx, ny, nz), dtype=torch.float32, device=dev)
 

@@ -81,6 +81,9 @@ typedef struct ttsweep_ctx ttsweep_ctx;
                                           which the distance gate of the STRIP kernel opens per
                                           pass; 0 switches the gate off (default: half the
                                           star's reach) */
+#define TTSWEEP_OPT_PAIR_MIN_STARTS 7 /* schedule only: the STRIP kernel relaxes units of two planes
+                                         (throughput) from this many starts per solve on, units of
+                                         one plane (latency) below */
 #define TTSWEEP_OPT_GATE_R0_MILLI 6   /* schedule only: gate radius of the first pass, cells x 1/1000
                                          (default: the star's reach + 1) */
 

@@ -24,9 +24,14 @@ def P(pkg):
 
 
 def gpu_converge(P, v, fs, starts, starstart=0, starstop=None, tts=None, kernel=None):
+    """kernel: 1 CELL, 2 STRIP (its own choice of unit size), 3 TILE; 21 / 22: STRIP with units
+    of one / two planes whatever the number of starts (latency / throughput mode)."""
     starts = np.asarray(starts, dtype=np.int32).reshape(-1, 3)
     with P.TravelTimeSolver(v.shape, fs, starstart, starstop) as sol:
-        if kernel is not None:
+        if kernel in (21, 22):
+            sol.set_option(P.OPT_KERNEL, 2)
+            sol.set_option(P.OPT_PAIR_MIN_STARTS, 1 << 20 if kernel == 21 else 0)
+        elif kernel is not None:
             sol.set_option(P.OPT_KERNEL, kernel)
         sol.set_velocity(v)
         if tts is None:
@@ -39,7 +44,7 @@ def gpu_converge(P, v, fs, starts, starstart=0, starstop=None, tts=None, kernel=
         return tts, rc, sol.stats()
 
 
-KERNELS = [pytest.param(1, id="cell"), pytest.param(2, id="strip")]
+KERNELS = [pytest.param(1, id="cell"), pytest.param(21, id="strip1"), pytest.param(22, id="strip2")]
 
 
 def tile_supports(offs):
@@ -63,7 +68,7 @@ def test_golden_cases_bit_exact(P, golden, kernel):
         fs = P.inputs.make_fs(offs)
         (tt,), rc, st = gpu_converge(P, golden.v, fs, [start], kernel=kernel)
         assert rc == 1, key
-        assert st["kernel_variant"] == kernel
+        assert st["kernel_variant"] == (2 if kernel > 20 else kernel)
         assert_bit_equal(tt, want, key)
         assert st["sweeps_total"] >= 2
         n += 1
@@ -156,7 +161,7 @@ def test_seeded_random_vs_oracle(P, oracle, shape, seed, kernel):
     start = [int(rng.integers(0, n)) for n in shape]
     want, _, _ = oracle.converge(v, oracle.make_star(offs), start, order=1)
     (tt,), _, st = gpu_converge(P, v, P.inputs.make_fs(offs), [start], kernel=kernel)
-    assert st["kernel_variant"] == kernel
+    assert st["kernel_variant"] == (2 if kernel > 20 else kernel)
     assert_bit_equal(tt, want, str(shape))
 
 
@@ -182,7 +187,8 @@ def test_fuzz_shapes_stars_starts_vs_oracle(P, oracle):
             offs = offs[np.any(offs != 0, axis=1)]
         nstart = int(rng.integers(1, 4))
         starts = np.stack([rng.integers(0, n, size=nstart) for n in shape], axis=1).astype(np.int32)
-        tts, _, st = gpu_converge(P, v, P.inputs.make_fs(offs), starts)
+        # the library's own choice of kernel, or the unit kernel forced into either mode
+        tts, _, st = gpu_converge(P, v, P.inputs.make_fs(offs), starts, kernel=[None, 21, 22][case % 3])
         ofs = oracle.make_star(offs)
         for start, tt in zip(starts, tts):
             want, _, _ = oracle.converge(v, ofs, start, order=1)
@@ -663,6 +669,6 @@ def test_duplicate_and_zero_offsets_in_the_star(P, oracle):
                      [0, 0, -3], [3, 3, 3]], np.int32)
     for start in ((9, 20, 11), (0, 0, 0)):
         want, _, _ = oracle.converge(v, oracle.make_star(offs), start, order=1)
-        for kernel in (1, 2):
+        for kernel in (1, 21, 22):
             (tt,), _, _ = gpu_converge(P, v, P.inputs.make_fs(offs), [start], kernel=kernel)
             assert_bit_equal(tt, want, f"{start} kernel {kernel}")

@@ -66,7 +66,7 @@ SYMBOLS = [
 ]
 
 OPT_TIMING, OPT_KERNEL, OPT_MAX_SWEEPS, OPT_MAX_BATCH = 1, 2, 3, 4
-OPT_GATE_SPEED_MILLI, OPT_GATE_R0_MILLI = 5, 6
+OPT_GATE_SPEED_MILLI, OPT_GATE_R0_MILLI, OPT_PAIR_MIN_STARTS = 5, 6, 7
 KERNEL_AUTO, KERNEL_CELL, KERNEL_STRIP, KERNEL_TILE = 0, 1, 2, 3
 
 

@@ -76,8 +76,12 @@ struct ttsweep_ctx {
     int n_fwd_entries = 0;
 
     // STRIP kernel: (da, db) columns of the star, dead-edge boxes
-    StripItem *d_strip_cols = nullptr;      // items of the star per staged plane (upload_strip_plan)
-    StripPlan plan{};
+    // STRIP kernel: the star's items for units of one plane (latency mode, few starts) and of
+    // two planes (throughput mode); `np` is the mode of the solve in progress
+    StripItem *d_strip_items[STRIP_PLANES] = {nullptr, nullptr};
+    StripPlan plans[STRIP_PLANES]{};
+    int np = STRIP_PLANES;
+    int pair_min_starts = 6;                // two-plane units from this many starts on (measured crossover)
     std::vector<std::array<int, 3>> special_offsets;   // device-axis offsets e: cell start - e owns a dead edge
     bool start_is_special = false;
     int max_box_cells = 0;                  // of the current solve
@@ -222,8 +226,10 @@ static void make_layout_strip(ttsweep_ctx *ctx)
     L.s1 = L.p[2];
     L.s0 = (long long)L.p[1] * L.p[2];
     L.cells = L.s0 * L.p[0];
-    ctx->plan.ra = r[0];
-    ctx->plan.rb = L.lo[1];
+    for (StripPlan &plan : ctx->plans) {
+        plan.ra = r[0];
+        plan.rb = L.lo[1];
+    }
 }
 
 // Padded layout for the TILE kernel: identity axis order (z stays the stride-1 axis),
@@ -303,10 +309,20 @@ static void make_layout(ttsweep_ctx *ctx)
     else make_layout_cell(ctx);
 }
 
+static int upload_strip_plan_np(ttsweep_ctx *ctx, int np);
+
 static int upload_strip_plan(ttsweep_ctx *ctx)
 {
+    for (int np = 1; np <= STRIP_PLANES; np++)
+        if (upload_strip_plan_np(ctx, np)) return -1;
+    return 0;
+}
+
+static int upload_strip_plan_np(ttsweep_ctx *ctx, int np)
+{
     const DevLayout &L = ctx->L;
-    StripPlan &plan = ctx->plan;
+    StripPlan &plan = ctx->plans[np - 1];
+    plan.np = np;
     // (da, db) columns of the pull star: all offsets that differ only in dc
     struct Col { int db; unsigned mask; float h[16]; };
     std::vector<std::vector<Col>> per_da(2 * plan.ra + 1);
@@ -330,10 +346,10 @@ static int upload_strip_plan(ttsweep_ctx *ctx)
         col->mask |= 1u << t;
         col->h[t] = e.h;
     }
-    // Items of staged plane p (plane 2A - ra + p of a unit that owns planes 2A, 2A + 1): own
-    // plane j relaxes it with plane offset da = p - ra - j.  Columns of the two own planes with
+    // Items of staged plane p (plane np A - ra + p of a unit that owns planes np A ..): own
+    // plane j relaxes it with plane offset da = p - ra - j.  Columns of two own planes with
     // the same row offset share an item (one window load serves both).
-    plan.nstaged = 2 * plan.ra + STRIP_PLANES;
+    plan.nstaged = 2 * plan.ra + np;
     std::vector<StripItem> flat;
     for (int p = 0; p < plan.nstaged; p++) {
         plan.first[p] = (int)flat.size();
@@ -341,7 +357,7 @@ static int upload_strip_plan(ttsweep_ctx *ctx)
         for (int j = 0; j < STRIP_PLANES; j++) {
             plan.nent[p][j] = 0;
             const int da = p - plan.ra - j;
-            if (da < -plan.ra || da > plan.ra) continue;
+            if (j >= np || da < -plan.ra || da > plan.ra) continue;
             for (const Col &c : per_da[da + plan.ra]) {
                 plan.nent[p][j] += __builtin_popcount(c.mask);
                 StripItem *it = nullptr;
@@ -379,12 +395,12 @@ static int upload_strip_plan(ttsweep_ctx *ctx)
     }
     plan.first[plan.nstaged] = (int)flat.size();
     if (flat.size() > 0xffff) return set_error("star has too many columns");
-    if (ctx->d_strip_cols) HIPCHK(hipFree(ctx->d_strip_cols));
-    ctx->d_strip_cols = nullptr;
+    StripItem *&d_items = ctx->d_strip_items[np - 1];
+    if (d_items) HIPCHK(hipFree(d_items));
+    d_items = nullptr;
     if (!flat.empty()) {
-        HIPCHK(hipMalloc((void **)&ctx->d_strip_cols, flat.size() * sizeof(StripItem)));
-        HIPCHK(hipMemcpy(ctx->d_strip_cols, flat.data(), flat.size() * sizeof(StripItem),
-                         hipMemcpyHostToDevice));
+        HIPCHK(hipMalloc((void **)&d_items, flat.size() * sizeof(StripItem)));
+        HIPCHK(hipMemcpy(d_items, flat.data(), flat.size() * sizeof(StripItem), hipMemcpyHostToDevice));
     }
     return 0;
 }
@@ -467,7 +483,7 @@ static int upload_star(ttsweep_ctx *ctx)
 // number of source units (see plan_pass_kernel).
 static size_t flag_words(const DevLayout &L)
 {
-    const size_t strip = 3 * (size_t)std::max(strip_units(L), 1) + 4;
+    const size_t strip = 3 * (size_t)std::max(strip_units(L, 1), 1) + 4;      // (one-plane units: the larger grid)
     const size_t tile = 2 * (size_t)tile_count(L.n[0], TILE_X) * tile_count(L.n[1], TILE_Y) * tile_count(L.n[2], TILE_Z);
     return std::max(strip, tile);
 }
@@ -530,7 +546,7 @@ static int timed_event(ttsweep_ctx *ctx, hipEvent_t *out)
 static int build_worklist(ttsweep_ctx *ctx, int nactive)
 {
     const auto t_begin = std::chrono::steady_clock::now();
-    const int nunits = strip_units(ctx->L);
+    const int nunits = strip_units(ctx->L, ctx->np);
     const int NX = ctx->nlists;
     std::vector<std::vector<int2>> per_xcd(NX);
     if (nactive >= NX) {
@@ -602,14 +618,15 @@ static void order_units(const ttsweep_ctx *ctx, const StartDesc &sd, std::vector
 {
     const DevLayout &L = ctx->L;
     const int btiles = strip_btiles(L), cstrips = strip_cstrips(L);
-    const int nunits = strip_units(L);
+    const int np = ctx->np;
+    const int nunits = strip_units(L, np);
     std::vector<std::pair<long long, int>> key(nunits);
     for (int t = 0; t < nunits; t++) {
         const int cs = t % cstrips, bt = (t / cstrips) % btiles, A = t / (cstrips * btiles);
         const long long cb = std::min(bt * STRIP_TB + STRIP_TB / 2, L.n[1] - 1);
         const long long cc = std::min(cs * STRIP_K + STRIP_K / 2, L.n[2] - 1);
-        // (distances in half cells: the unit's two planes are centred between them)
-        const long long da = 2 * (STRIP_PLANES * A - sd.sa) + (STRIP_PLANES - 1), db = 2 * (cb - sd.sb), dc = 2 * (cc - sd.sc);
+        // (distances in half cells: a unit of two planes is centred between them)
+        const long long da = 2 * (np * A - sd.sa) + (np - 1), db = 2 * (cb - sd.sb), dc = 2 * (cc - sd.sc);
         key[t] = {da * da + db * db + dc * dc, t};
     }
     std::sort(key.begin(), key.end());
@@ -636,7 +653,7 @@ static int launch_pass(ttsweep_ctx *ctx, int nactive, int nstart, int *d_changed
     if (ctx->kernel == TTSWEEP_KERNEL_STRIP) {
         HIPCHK(launch_plan_pass(ctx->L, ctx->d_starts, ctx->d_worklist, ctx->worklist_len, d_changed,
                                 ctx->d_unitq, (int)ctx->unitq_cap, ctx->nlists, ctx->d_unitq_ctrl,
-                                ctx->plan, ctx->pass_index & 1, gate_r2(ctx), ctx->stream));
+                                ctx->plans[ctx->np - 1], ctx->pass_index & 1, gate_r2(ctx), ctx->stream));
         UnitPassTail tail;
         tail.active = ctx->d_active;
         tail.nactive = nactive;
@@ -647,8 +664,9 @@ static int launch_pass(ttsweep_ctx *ctx, int nactive, int nstart, int *d_changed
         tail.changed_host = h_changed_slot;
         tail.changed_next = d_changed_next;
         HIPCHK(launch_sweep_units(ctx->L, ctx->d_v, ctx->d_starts, ctx->d_unitq, (int)ctx->unitq_cap,
-                                  ctx->nlists, ctx->d_unitq_ctrl, ctx->unitq_blocks, d_changed, ctx->d_strip_cols,
-                                  ctx->plan, ctx->pass_index & 1, tail, ctx->stream));
+                                  ctx->nlists, ctx->d_unitq_ctrl, ctx->unitq_blocks, d_changed,
+                                  ctx->d_strip_items[ctx->np - 1], ctx->plans[ctx->np - 1], ctx->pass_index & 1,
+                                  tail, ctx->stream));
     } else if (ctx->kernel == TTSWEEP_KERNEL_TILE) {
         // one ordering sweep: the tile hyperplanes in stream order, one launch each
         TileSweep P;
@@ -811,7 +829,7 @@ void ttsweep_destroy(ttsweep_ctx *ctx)
     (void)hipFree(ctx->d_v);
     (void)hipFree(ctx->d_cell_entries);
     (void)hipFree(ctx->d_fwd_entries);
-    (void)hipFree(ctx->d_strip_cols);
+    for (StripItem *d : ctx->d_strip_items) (void)hipFree(d);
     (void)hipFree(ctx->d_T);
     (void)hipFree(ctx->d_starts);
     (void)hipFree(ctx->d_active);
@@ -875,6 +893,10 @@ int ttsweep_set_option(ttsweep_ctx *ctx, int key, long long value)
     case TTSWEEP_OPT_GATE_SPEED_MILLI:
         if (value < 0) return set_error("gate speed must be >= 0");
         ctx->gate_speed = (double)value / 1000.0;
+        return 0;
+    case TTSWEEP_OPT_PAIR_MIN_STARTS:
+        if (value < 0) return set_error("start count must be >= 0");
+        ctx->pair_min_starts = (int)std::min<long long>(value, 1 << 30);
         return 0;
     case TTSWEEP_OPT_GATE_R0_MILLI:
         if (value < 0) return set_error("gate start radius must be >= 0");
@@ -962,6 +984,10 @@ static int solve_device_body(ttsweep_ctx *ctx, int nstart, const ttsweep_start *
 {
     const DevLayout &L = ctx->L;
     HIPCHK(hipEventRecord(ctx->ev_solve0, ctx->stream));
+    // units of two planes when there are starts enough to fill the machine with them
+    const int np = nstart >= ctx->pair_min_starts ? STRIP_PLANES : 1;
+    if (np != ctx->np) ctx->unit_order_key.assign(ctx->unit_order_key.size(), -1);     // orders belong to the other unit grid
+    ctx->np = np;
 
     for (int s = 0; s < nstart; s++) {
         const int u[3] = {starts[s].i, starts[s].j, starts[s].k};

@@ -78,12 +78,16 @@ constexpr int STRIP_CF = 8;                         // halo in front of a strip 
 constexpr int STRIP_W = STRIP_K + 2 * STRIP_CF;     // neighbour window per (cell strip, column)
 constexpr int STRIP_MAX_RA = 7;                     // plane offsets handled: |da| <= 7
 
-// A unit of the STRIP kernel owns TWO neighbouring planes (2A, 2A + 1) of one lane tile and
-// strip: every staged neighbour plane q is used twice, with plane offset q - 2A for the first
-// own plane and q - 2A - 1 for the second.  An item is one slab row offset db of a staged plane
-// together with the offsets (differing only in dc) that either own plane relaxes against it:
-// one register window is loaded per item and serves both planes.
-constexpr int STRIP_PLANES = 2;                         // own planes per unit
+// A unit of the STRIP kernel owns np = 1 or 2 neighbouring planes (np A .. np A + np - 1) of one
+// lane tile and strip.  With two, every staged neighbour plane q is used twice, with plane
+// offset q - 2A for the first own plane and q - 2A - 1 for the second: slab traffic, barriers,
+// window loads and per-unit overheads are shared by two planes of output (the throughput
+// mode, many starts).  With one, units are half as long and twice as many (the latency mode:
+// few starts cannot fill the machine with long units, and a pass is never shorter than its
+// longest unit).  An item is one slab row offset db of a staged plane together with the
+// offsets (differing only in dc) that either own plane relaxes against it: one register
+// window is loaded per item and serves both planes.
+constexpr int STRIP_PLANES = 2;                         // own planes per unit, at most
 constexpr int STRIP_STAGED = 2 * STRIP_MAX_RA + STRIP_PLANES;   // staged planes per unit, at most
 
 struct StripItem {
@@ -95,7 +99,8 @@ struct StripItem {
 
 struct StripPlan {
     int ra, rb;                         // max |da|, max |db| over the star
-    int nstaged;                        // 2 ra + STRIP_PLANES: staged plane p is plane 2A - ra + p
+    int np;                             // own planes per unit (1 or 2)
+    int nstaged;                        // 2 ra + np: staged plane p is plane np A - ra + p
     int first[STRIP_STAGED + 1];        // items of staged plane p are [first[p], first[p+1])
     int nent[STRIP_STAGED][STRIP_PLANES];   // offsets own plane j relaxes against staged plane p
     // the items of a staged plane are laid out so that wave w of the workgroup relaxes
@@ -103,11 +108,12 @@ struct StripPlan {
     unsigned char wsplit[STRIP_STAGED][STRIP_NS + 1];
 };
 
-// Unit grid of one start: plane pairs along a x lane tiles along b x strips along c.
-__host__ __device__ inline int strip_apairs(const DevLayout &L) { return (L.n[0] + STRIP_PLANES - 1) / STRIP_PLANES; }
+// Unit grid of one start: plane groups (np planes each) along a x lane tiles along b x strips
+// along c.
+__host__ __device__ inline int strip_agroups(const DevLayout &L, int np) { return (L.n[0] + np - 1) / np; }
 __host__ __device__ inline int strip_btiles(const DevLayout &L) { return (L.n[1] + STRIP_TB - 1) / STRIP_TB; }
 __host__ __device__ inline int strip_cstrips(const DevLayout &L) { return (L.n[2] + STRIP_K - 1) / STRIP_K; }
-__host__ __device__ inline int strip_units(const DevLayout &L) { return strip_apairs(L) * strip_btiles(L) * strip_cstrips(L); }
+__host__ __device__ inline int strip_units(const DevLayout &L, int np) { return strip_agroups(L, np) * strip_btiles(L) * strip_cstrips(L); }
 
 // "changed" word of a start and pass: bit 0 = a travel time improved, bit 1 = units are held
 // back by the distance gate (the start is not converged, but nothing has improved for it).

@@ -480,32 +480,36 @@ __device__ __forceinline__ void relax_dispatch(unsigned mask, const float (&h)[1
     }
 }
 
+// Activity flags are kept per (plane, lane tile, strip) whatever the unit size: a unit of two
+// planes sets and clears the words of its planes separately, so that a staged plane counts
+// as changed only when that very plane improved.
+__host__ __device__ inline int strip_flag_words(const DevLayout &L) { return L.n[0] * strip_btiles(L) * strip_cstrips(L); }
+
 __global__ void __launch_bounds__(256)
-init_tile_flags_kernel(int *__restrict__ flags, int nunits, int start_unit)
+init_tile_flags_kernel(int *__restrict__ flags, int nflag, int start_flag)
 {
     const int t = blockIdx.x * 256 + threadIdx.x;
-    if (t >= nunits) return;
+    if (t >= nflag) return;
     flags[t] = 0;
-    flags[nunits + t] = t == start_unit ? FLAG_ALL : 0;
-    flags[2 * nunits + t] = 0;          // pend[]: nothing held back yet
-    if (t == 0) flags[3 * nunits] = 1;  // one source unit: the distance gate applies
+    flags[nflag + t] = t == start_flag ? FLAG_ALL : 0;
+    flags[2 * nflag + t] = 0;           // pend[] (per unit): nothing held back yet
+    if (t == 0) flags[3 * nflag] = 1;   // one source: the distance gate applies
 }
 
-// Flags for a box that arrives with values in it: a unit counts as "changed" when it holds
-// a finite travel time (only those can improve anything).  One wave per unit.
+// Flags for a box that arrives with values in it: a (plane, lane tile, strip) counts as
+// "changed" when it holds a finite travel time (only those can improve anything).  One wave
+// per flag word.
 __global__ void __launch_bounds__(64)
 init_tile_flags_box_kernel(DevLayout L, const float *__restrict__ T, int *__restrict__ flags,
-                           int nunits, int btiles, int cstrips)
+                           int nflag, int btiles, int cstrips)
 {
     int u = blockIdx.x;
     const int cs = u % cstrips;  u /= cstrips;
     const int bt = u % btiles;   u /= btiles;
-    const int A = u;
+    const int a = u;
     const int lane = threadIdx.x;
     bool finite = false;
-    for (int j = 0; j < STRIP_PLANES; j++) {
-        const int a = STRIP_PLANES * A + j;
-        if (a >= L.n[0] || bt * STRIP_TB + lane >= L.n[1]) continue;
+    if (bt * STRIP_TB + lane < L.n[1]) {
         const long long g = (long long)(a + L.lo[0]) * L.s0
                           + (long long)(bt * STRIP_TB + lane + L.lo[1]) * L.s1 + (cs * STRIP_K + L.lo[2]);
 #pragma unroll
@@ -514,27 +518,26 @@ init_tile_flags_box_kernel(DevLayout L, const float *__restrict__ T, int *__rest
     const bool any = __ballot(finite) != 0ull;
     if (lane == 0) {
         flags[blockIdx.x] = 0;
-        flags[nunits + blockIdx.x] = any ? FLAG_ALL : 0;
-        flags[2 * nunits + blockIdx.x] = 0;
-        if (any) atomicAdd(&flags[3 * nunits], 1);      // number of source units
+        flags[nflag + blockIdx.x] = any ? FLAG_ALL : 0;
+        flags[2 * nflag + blockIdx.x] = 0;
+        if (any) atomicAdd(&flags[3 * nflag], 1);       // number of sources
     }
 }
 
-hipError_t launch_init_tile_flags(const DevLayout &L, const StartDesc &sd, bool from_box,
-                                  hipStream_t st)
+hipError_t launch_init_tile_flags(const DevLayout &L, const StartDesc &sd, bool from_box, hipStream_t st)
 {
     const int btiles = strip_btiles(L), cstrips = strip_cstrips(L);
-    const int nunits = strip_units(L);
+    const int nflag = strip_flag_words(L);
     if (from_box) {
-        hipError_t e = hipMemsetAsync(sd.tile_flags + 3 * (size_t)nunits, 0, sizeof(int), st);
+        hipError_t e = hipMemsetAsync(sd.tile_flags + 3 * (size_t)nflag, 0, sizeof(int), st);
         if (e != hipSuccess) return e;
-        hipLaunchKernelGGL(init_tile_flags_box_kernel, dim3(nunits), dim3(64), 0, st, L, sd.T,
-                           sd.tile_flags, nunits, btiles, cstrips);
+        hipLaunchKernelGGL(init_tile_flags_box_kernel, dim3(nflag), dim3(64), 0, st, L, sd.T,
+                           sd.tile_flags, nflag, btiles, cstrips);
         return hipGetLastError();
     }
-    const int start_unit = ((sd.sa / STRIP_PLANES) * btiles + sd.sb / STRIP_TB) * cstrips + sd.sc / STRIP_K;
-    hipLaunchKernelGGL(init_tile_flags_kernel, dim3((nunits + 255) / 256), dim3(256), 0, st,
-                       sd.tile_flags, nunits, start_unit);
+    const int start_flag = (sd.sa * btiles + sd.sb / STRIP_TB) * cstrips + sd.sc / STRIP_K;
+    hipLaunchKernelGGL(init_tile_flags_kernel, dim3((nflag + 255) / 256), dim3(256), 0, st,
+                       sd.tile_flags, nflag, start_flag);
     return hipGetLastError();
 }
 
@@ -569,7 +572,7 @@ hipError_t launch_init_tile_flags(const DevLayout &L, const StartDesc &sd, bool 
 __global__ void __launch_bounds__(256)
 plan_pass_kernel(DevLayout L, const StartDesc *__restrict__ starts, const int2 *__restrict__ work,
                  long long nwork, int *__restrict__ changed, int4 *__restrict__ lists, int list_cap,
-                 int *__restrict__ ctrl, int nlists, int ra, int btiles, int cstrips, int parity,
+                 int *__restrict__ ctrl, int nlists, int ra, int np, int btiles, int cstrips, int parity,
                  float gate_r2)
 {
     // wave W handles 64 consecutive entries of ONE XCD's sub-list, so that a wave-level
@@ -588,16 +591,15 @@ plan_pass_kernel(DevLayout L, const StartDesc *__restrict__ starts, const int2 *
     }
     if (unit >= 0) {
         const StartDesc sd = starts[s];
-        const int nunits = strip_apairs(L) * btiles * cstrips;
+        const int nflag = L.n[0] * btiles * cstrips;
         int u = unit;
         const int cs = u % cstrips;  u /= cstrips;
         const int bt = u % btiles;   u /= btiles;
-        const int a0 = STRIP_PLANES * u;        // first own plane
-        const int *__restrict__ prev_flags = sd.tile_flags + (1 - parity) * nunits;
-        for (int p = 0; p < 2 * ra + STRIP_PLANES; p++) {
+        const int a0 = np * u;                  // first own plane
+        const int *__restrict__ prev_flags = sd.tile_flags + (1 - parity) * nflag;
+        for (int p = 0; p < 2 * ra + np; p++) {
             const int q = a0 - ra + p;          // staged plane
             if (q < 0 || q >= L.n[0]) continue;
-            const int qa = q / STRIP_PLANES;    // the unit row that owns it
             bool due = false;
             for (int r = 0; r < 9; r++) {
                 const int nb = bt + r / 3 - 1, nc = cs + r % 3 - 1;
@@ -605,19 +607,19 @@ plan_pass_kernel(DevLayout L, const StartDesc *__restrict__ starts, const int2 *
                 const int need = flag_bit(r / 3 == 0 ? ZONE_HI : r / 3 == 2 ? ZONE_LO : ZONE_ANY,
                                           r % 3 == 0 ? ZONE_HI : r % 3 == 2 ? ZONE_LO : ZONE_ANY);
                 if (nb >= 0 && nb < btiles && nc >= 0 && nc < cstrips
-                    && (prev_flags[(qa * btiles + nb) * cstrips + nc] & need))
+                    && (prev_flags[(q * btiles + nb) * cstrips + nc] & need))
                     due = true;
             }
             if (due) planes |= 1u << p;
         }
         // distance gate and held-back plane bits
-        unsigned *__restrict__ pend = reinterpret_cast<unsigned *>(sd.tile_flags + 2 * nunits);
+        unsigned *__restrict__ pend = reinterpret_cast<unsigned *>(sd.tile_flags + 2 * nflag);
         const int b0 = bt * STRIP_TB, cb0 = cs * STRIP_K;
         const int tb_eff = min(STRIP_TB, L.n[1]);
-        const float da_ = (float)max(max(a0 - sd.sa, sd.sa - (a0 + STRIP_PLANES - 1)), 0);
+        const float da_ = (float)max(max(a0 - sd.sa, sd.sa - (a0 + np - 1)), 0);
         const float db_ = (float)max(max(b0 - sd.sb, sd.sb - (b0 + tb_eff - 1)), 0);
         const float dc_ = (float)max(max(cb0 - sd.sc, sd.sc - (cb0 + STRIP_K - 1)), 0);
-        const bool gated = sd.tile_flags[3 * nunits] == 1;
+        const bool gated = sd.tile_flags[3 * nflag] == 1;
         const bool open = !gated || da_ * da_ + db_ * db_ + dc_ * dc_ <= gate_r2;
         const unsigned held = pend[unit];
         if (!open) {
@@ -628,7 +630,8 @@ plan_pass_kernel(DevLayout L, const StartDesc *__restrict__ starts, const int2 *
             planes |= held;
             if (held) pend[unit] = 0;
         }
-        sd.tile_flags[parity * nunits + unit] = 0;      // improvements of this pass are OR-ed in
+        for (int j = 0; j < np; j++)                    // improvements of this pass are OR-ed in
+            if (a0 + j < L.n[0]) sd.tile_flags[parity * nflag + ((a0 + j) * btiles + bt) * cstrips + cs] = 0;
     }
     const unsigned long long due_lanes = __ballot(planes != 0);
     if (due_lanes == 0ull) return;
@@ -684,8 +687,8 @@ __device__ __forceinline__ void relax_special_cell(const DevLayout &L, const flo
         T[ci] = best;
         atomicOr(&changed[s], CHANGED_IMPROVED);
         const int btiles = strip_btiles(L), cstrips = strip_cstrips(L);
-        atomicOr(sd.tile_flags + parity * strip_units(L)
-                 + ((a / STRIP_PLANES) * btiles + b / STRIP_TB) * cstrips + c / STRIP_K, FLAG_ALL);
+        atomicOr(sd.tile_flags + parity * strip_flag_words(L)
+                 + (a * btiles + b / STRIP_TB) * cstrips + c / STRIP_K, FLAG_ALL);
     }
 }
 
@@ -767,7 +770,7 @@ void prof_dump()
 #endif
 int units_wgs_per_cu() { return TTSWEEP_WGS_GRID; }
 
-template <int K>
+template <int K, int NP>
 __global__ void __launch_bounds__(STRIP_TB *STRIP_NS, TTSWEEP_WGS_PER_CU)
 sweep_units_kernel(DevLayout L, const float *__restrict__ v, const StartDesc *__restrict__ starts,
                    const int4 *__restrict__ lists, int list_cap, int nlists, int *__restrict__ ctrl,
@@ -775,10 +778,10 @@ sweep_units_kernel(DevLayout L, const float *__restrict__ v, const StartDesc *__
                    int btiles, int cstrips, int parity, UnitPassTail tail)
 {
     constexpr int NS = STRIP_NS;
-    constexpr int NP = STRIP_PLANES;
     constexpr int W = K + 2 * STRIP_CF;
     static_assert(K == STRIP_K && STRIP_W == 32 && W == 32, "slab rows are 8 float4 wide");
-    static_assert(NP == 2 && NS == 4, "two own planes, four waves: wave w finishes half a row of plane w / 2");
+    static_assert(NP >= 1 && NP <= STRIP_PLANES && (NP * K) % NS == 0 && K % (NP * K / NS) == 0,
+                  "every wave finishes a whole number of cells of one own plane");
     extern __shared__ __attribute__((aligned(16))) float smem[];
     int *head = reinterpret_cast<int *>(smem);      // [0], [1]: queue index handed to the workgroup
 
@@ -791,7 +794,7 @@ sweep_units_kernel(DevLayout L, const float *__restrict__ v, const StartDesc *__
     const int lane_r = min(lane, tb_eff - 1);
     const int rows8 = (rows + 7) & ~7;
     constexpr int slab_floats = SLAB_BYTES / 4;     // v rows, then T rows
-    const int nunits = strip_apairs(L) * btiles * cstrips;
+    const int nflag = L.n[0] * btiles * cstrips;
     float *slabs = smem + STRIP_LDS_HEAD;           // two slabs (double buffer)
     float *comb = smem + STRIP_LDS_HEAD;            // [wave][plane][cell][lane], aliases the slabs
     const int nitems = plan.first[plan.nstaged];
@@ -913,17 +916,17 @@ sweep_units_kernel(DevLayout L, const float *__restrict__ v, const StartDesc *__
 #pragma unroll
             for (int p = 0; p < K / 2 - 1; p++) vco[jp][p] = f32x2{vce[jp][p].y, vce[jp][p + 1].x};
         }
-        // what this wave will finish and store at the end: cells 8 (wave & 1) .. + 7 of own
-        // plane wave / 2; their values before this unit's relaxation stay in registers
+        // what this wave will finish and store at the end: CQ consecutive cells of one own
+        // plane; their values before this unit's relaxation stay in registers
         constexpr int CQ = NP * K / NS;     // cells per wave in the epilogue
-        static_assert(CQ * 2 == K, "a wave finishes half a row of one own plane");
-        const int fin_plane = wave >> 1, fin_q0 = (wave & 1) * CQ;
+        const int fin_plane = wave * CQ / K, fin_q0 = wave * CQ % K;
         float told[CQ];
 #pragma unroll
-        for (int qq = 0; qq < CQ; qq++) {
-            const float lo = fin_plane ? acc[1][qq] : acc[0][qq];
-            const float hi = fin_plane ? acc[1][CQ + qq] : acc[0][CQ + qq];
-            told[qq] = (wave & 1) ? hi : lo;
+        for (int qq = 0; qq < CQ; qq++) {   // (wave-uniform selects between compile-time registers)
+#define ACC_FLAT(e) acc[(e) / K][(e) % K]
+            told[qq] = wave == 0 ? ACC_FLAT(qq) : wave == 1 ? ACC_FLAT(CQ + qq)
+                     : wave == 2 ? ACC_FLAT(2 * CQ + qq) : ACC_FLAT(3 * CQ + qq);
+#undef ACC_FLAT
         }
 
         PROF_T(t_pro);
@@ -960,7 +963,7 @@ sweep_units_kernel(DevLayout L, const float *__restrict__ v, const StartDesc *__
                 const ItemHdr nxt = load_hdr(items, ii + 1 < iend ? ii + 1 : next_first);
                 float h0[16], h1[16];
 #pragma unroll
-                for (int t = 1; t < 16; t++) { h0[t] = item->h[0][t]; h1[t] = item->h[1][t]; }
+                for (int t = 1; t < 16; t++) { h0[t] = item->h[0][t]; h1[t] = NP > 1 ? item->h[1][t] : 0.0f; }
                 const int rowoff = cur.rowoff;
                 const unsigned m0 = cur.m0, m1 = cur.m1;
                 // the neighbour window of this item's slab row, both arrays, into registers:
@@ -989,7 +992,7 @@ sweep_units_kernel(DevLayout L, const float *__restrict__ v, const StartDesc *__
                     tN2[2 * jj] = f32x2{yw[jj].x, yw[jj].y}; tN2[2 * jj + 1] = f32x2{yw[jj].z, yw[jj].w};
                 }
                 relax_dispatch<K>(m0, h0, vN2, tN2, vce[0], vco[0], acc[0]);
-                relax_dispatch<K>(m1, h1, vN2, tN2, vce[1], vco[1], acc[1]);
+                if (NP > 1) relax_dispatch<K>(m1, h1, vN2, tN2, vce[NP - 1], vco[NP - 1], acc[NP - 1]);
                 cur = nxt;
             }
             if (ibeg >= iend) cur = load_hdr(items, next_first);    // (no item of this plane was ours)
@@ -1040,7 +1043,7 @@ sweep_units_kernel(DevLayout L, const float *__restrict__ v, const StartDesc *__
 #pragma unroll
         for (int w = 32; w >= 1; w >>= 1) improved |= __shfl_xor(improved, w);
         if (lane == 0 && improved) {
-            atomicOr(tile_flags + parity * nunits + my_unit, improved);
+            atomicOr(tile_flags + parity * nflag + (a * btiles + bt) * cstrips + cs, improved);
             atomicOr(&changed[s], CHANGED_IMPROVED);
         }
 #ifdef TTSWEEP_PROFILE
@@ -1100,7 +1103,7 @@ hipError_t launch_plan_pass(const DevLayout &L, const StartDesc *starts, const i
     const long long nblocks = (waves + 3) / 4;
     if (nblocks > 0x7fffffffLL) return hipErrorInvalidValue;
     hipLaunchKernelGGL(plan_pass_kernel, dim3((unsigned)nblocks), dim3(256), 0, st, L, starts, work,
-                       nwork, changed, lists, list_cap, ctrl, nlists, plan.ra, btiles, strip_cstrips(L),
+                       nwork, changed, lists, list_cap, ctrl, nlists, plan.ra, plan.np, btiles, strip_cstrips(L),
                        parity, gate_r2);
     return hipGetLastError();
 }
@@ -1112,8 +1115,9 @@ hipError_t launch_sweep_units(const DevLayout &L, const float *v, const StartDes
 {
     if (nblocks <= 0 || nlists < 1 || nlists > UNITQ_LISTS)
         return hipErrorInvalidValue;                    // (the last workgroup closes the pass)
+    if (plan.np < 1 || plan.np > STRIP_PLANES) return hipErrorInvalidValue;
     const int btiles = strip_btiles(L);
-    auto kern = sweep_units_kernel<STRIP_K>;
+    auto kern = plan.np == 1 ? sweep_units_kernel<STRIP_K, 1> : sweep_units_kernel<STRIP_K, 2>;
     const size_t lds = units_lds_bytes(plan, L.n[1]);
     if (lds > 48 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
