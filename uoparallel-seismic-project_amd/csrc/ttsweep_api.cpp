@@ -81,7 +81,7 @@ struct ttsweep_ctx {
     StripItem *d_strip_items[STRIP_PLANES] = {nullptr, nullptr};
     StripPlan plans[STRIP_PLANES]{};
     int np = STRIP_PLANES;
-    int pair_min_starts = 6;                // two-plane units from this many starts on (measured crossover)
+    int pair_min_starts = 8;                // two-plane units from this many starts on (measured crossover)
     std::vector<std::array<int, 3>> special_offsets;   // device-axis offsets e: cell start - e owns a dead edge
     bool start_is_special = false;
     int max_box_cells = 0;                  // of the current solve

@@ -463,6 +463,71 @@ __device__ __forceinline__ void relax_window(unsigned rt_mask, const float (&h)[
     }
 }
 
+// The float4 chunks of a K + 16 wide window that the offsets `mask` read (elements t .. t+K-1).
+template <int K>
+__host__ __device__ constexpr unsigned window_chunks(unsigned mask)
+{
+    unsigned chunks = 0;
+    for (int t = 1; t < 2 * STRIP_CF; t++)
+        if (mask & (1u << t))
+            for (int j = 0; j < (K + 2 * STRIP_CF) / 4; j++)
+                if (4 * j + 3 >= t && 4 * j <= t + K - 1) chunks |= 1u << j;
+    return chunks;
+}
+
+// The neighbour window of one slab row, both arrays, into registers: chunk j of the row is
+// float4 j ^ swizzle (stage_slab); one v_xad_u32 per float4 pair, the T row sits at a
+// compile-time distance behind the v row.  CHUNKS: the float4s that are needed (others stand
+// in for a loaded one: no instructions).
+template <int K, unsigned CHUNKS>
+__device__ __forceinline__ void load_window(const char *prow, unsigned swb,
+                                            f32x2 (&vN2)[(K + 2 * STRIP_CF) / 2], f32x2 (&tN2)[(K + 2 * STRIP_CF) / 2])
+{
+    constexpr int W = K + 2 * STRIP_CF;
+    static_assert(W / 4 == 8 && CHUNKS != 0u, "the window is 8 float4 wide");
+    f32x4 xw[W / 4], yw[W / 4];
+#pragma unroll
+    for (int jj = 0; jj < W / 4; jj++) {
+        if (CHUNKS & (1u << jj)) {
+            const char *at = prow + (swb ^ (unsigned)(16 * jj));
+            xw[jj] = *reinterpret_cast<const f32x4 *>(at);
+            yw[jj] = *reinterpret_cast<const f32x4 *>(at + SLAB_T_BYTES);
+        }
+    }
+    constexpr int JF = __builtin_ctz(CHUNKS);       // a chunk that is read
+#pragma unroll
+    for (int jj = 0; jj < W / 4; jj++)
+        if (!(CHUNKS & (1u << jj))) { xw[jj] = xw[JF]; yw[jj] = yw[JF]; }
+    // All loads are issued before the first value is used, and whole float4s are kept: partly
+    // used chunks would otherwise be narrowed to ds_read2_b64 pairs (8 LDS cycles instead of 4).
+    asm volatile("" :: "v"(xw[0]), "v"(xw[1]), "v"(xw[2]), "v"(xw[3]), "v"(xw[4]), "v"(xw[5]),
+                 "v"(xw[6]), "v"(xw[7]), "v"(yw[0]), "v"(yw[1]), "v"(yw[2]), "v"(yw[3]), "v"(yw[4]),
+                 "v"(yw[5]), "v"(yw[6]), "v"(yw[7]));
+#pragma unroll
+    for (int jj = 0; jj < W / 4; jj++) {
+        vN2[2 * jj] = f32x2{xw[jj].x, xw[jj].y}; vN2[2 * jj + 1] = f32x2{xw[jj].z, xw[jj].w};
+        tN2[2 * jj] = f32x2{yw[jj].x, yw[jj].y}; tN2[2 * jj + 1] = f32x2{yw[jj].z, yw[jj].w};
+    }
+}
+
+// Units of one plane: window load and relaxation in one routine per offset set, so that only
+// the float4s the set reads are loaded.
+template <int K>
+__device__ __forceinline__ void relax_item_single(unsigned mask, const float (&h)[16], const char *prow, unsigned swb,
+                                                  const f32x2 (&vce)[K / 2], const f32x2 (&vco)[K / 2 - 1],
+                                                  float (&acc)[K])
+{
+    f32x2 vN2[(K + 2 * STRIP_CF) / 2], tN2[(K + 2 * STRIP_CF) / 2];
+    switch (mask) {
+    case 0u: break;
+#define STRIP_MASK_CASE(m) \
+    case m: load_window<K, window_chunks<K>(m)>(prow, swb, vN2, tN2); relax_window<K, m>(mask, h, vN2, tN2, vce, vco, acc); break;
+#include "strip_masks.inc"
+#undef STRIP_MASK_CASE
+    default: load_window<K, 0xffu>(prow, swb, vN2, tN2); relax_window<K, 0u>(mask, h, vN2, tN2, vce, vco, acc); break;
+    }
+}
+
 // The straight-line routine of the item's offset set, or the generic one.
 template <int K>
 __device__ __forceinline__ void relax_dispatch(unsigned mask, const float (&h)[16],
@@ -966,33 +1031,17 @@ sweep_units_kernel(DevLayout L, const float *__restrict__ v, const StartDesc *__
                 for (int t = 1; t < 16; t++) { h0[t] = item->h[0][t]; h1[t] = NP > 1 ? item->h[1][t] : 0.0f; }
                 const int rowoff = cur.rowoff;
                 const unsigned m0 = cur.m0, m1 = cur.m1;
-                // the neighbour window of this item's slab row, both arrays, into registers:
-                // slab rows are XOR-swizzled (stage_slab); one v_xad_u32 per float4 pair, the T
-                // row sits at a compile-time distance behind the v row
                 const int row = lane_r + rb + rowoff;
                 const char *prow = reinterpret_cast<const char *>(sv) + row * (STRIP_W * 4);
                 const unsigned swb = (unsigned)slab_swizzle(row) << 4;
-                f32x4 xw[W / 4], yw[W / 4];
-#pragma unroll
-                for (int jj = 0; jj < W / 4; jj++) {
-                    const char *at = prow + (swb ^ (unsigned)(16 * jj));
-                    xw[jj] = *reinterpret_cast<const f32x4 *>(at);
-                    yw[jj] = *reinterpret_cast<const f32x4 *>(at + SLAB_T_BYTES);
+                if (NP == 1) {
+                    relax_item_single<K>(m0, h0, prow, swb, vce[0], vco[0], acc[0]);
+                } else {
+                    f32x2 vN2[W / 2], tN2[W / 2];       // window element w is pair w/2, half w&1
+                    load_window<K, 0xffu>(prow, swb, vN2, tN2);
+                    relax_dispatch<K>(m0, h0, vN2, tN2, vce[0], vco[0], acc[0]);
+                    relax_dispatch<K>(m1, h1, vN2, tN2, vce[NP - 1], vco[NP - 1], acc[NP - 1]);
                 }
-                // All loads are issued before the first value is used, and whole float4s are
-                // kept: partly used chunks would otherwise be narrowed to ds_read2_b64 pairs
-                // (8 LDS cycles instead of 4).
-                asm volatile("" :: "v"(xw[0]), "v"(xw[1]), "v"(xw[2]), "v"(xw[3]), "v"(xw[4]), "v"(xw[5]),
-                             "v"(xw[6]), "v"(xw[7]), "v"(yw[0]), "v"(yw[1]), "v"(yw[2]), "v"(yw[3]), "v"(yw[4]),
-                             "v"(yw[5]), "v"(yw[6]), "v"(yw[7]));
-                f32x2 vN2[W / 2], tN2[W / 2];       // window element w is pair w/2, half w&1
-#pragma unroll
-                for (int jj = 0; jj < W / 4; jj++) {
-                    vN2[2 * jj] = f32x2{xw[jj].x, xw[jj].y}; vN2[2 * jj + 1] = f32x2{xw[jj].z, xw[jj].w};
-                    tN2[2 * jj] = f32x2{yw[jj].x, yw[jj].y}; tN2[2 * jj + 1] = f32x2{yw[jj].z, yw[jj].w};
-                }
-                relax_dispatch<K>(m0, h0, vN2, tN2, vce[0], vco[0], acc[0]);
-                if (NP > 1) relax_dispatch<K>(m1, h1, vN2, tN2, vce[NP - 1], vco[NP - 1], acc[NP - 1]);
                 cur = nxt;
             }
             if (ibeg >= iend) cur = load_hdr(items, next_first);    // (no item of this plane was ours)
