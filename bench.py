@@ -353,7 +353,7 @@ def main():
         gbs = alg_bytes / kern_s / 1e9 if kern_s > 0 else 0.0
         tfl = flops / kern_s / 1e12 if kern_s > 0 else 0.0
         kname = {1: "sweep_cell_kernel", 2: "plan_pass_kernel + sweep_units_kernel (one pass)",
-                 3: "tile_sweep_kernel (one tile hyperplane of an ordering sweep)"}[st["kernel_variant"]]
+                 3: "tile_plan_kernel + tile_sweep_kernel (one tile hyperplane of an ordering sweep)"}[st["kernel_variant"]]
         common = {"kernel": kname, "launches": int(launches), "avg_launch_ms": st["sweep_kernel_ms"] / launches,
                   "algorithmic_bytes_per_launch": alg_bytes / launches,
                   "algorithmic_flops_per_launch": flops / launches,

@@ -1,7 +1,7 @@
 """Experiment: time ONE full ordering sweep of the TILE kernel over every tile (a converged box
 solved again: every tile is due once, nothing improves, nothing is stored)."""
 import sys, os, time
-sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "."))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch, ttsweep_pkg
 P = ttsweep_pkg.load()
 shape = tuple(int(x) for x in sys.argv[1].split(","))

@@ -1048,6 +1048,7 @@ static int solve_device_body(ttsweep_ctx *ctx, int nstart, const ttsweep_start *
     // passes.  A start whose pass-k words show no change is converged; the pass k+1
     // that was launched speculatively for it finds all its units inactive.
     std::vector<int> sweeps(nstart, 0);
+    std::vector<char> done(nstart, 0);          // converged: the pass launched one ahead for it is not counted
 #ifdef TTSWEEP_DEBUG_ENV
     const bool trace = getenv("TTSWEEP_TRACE") != nullptr;
 #else
@@ -1099,13 +1100,15 @@ static int solve_device_body(ttsweep_ctx *ctx, int nstart, const ttsweep_start *
         }
         bool dropped = false;
         for (int s : snapshot[slot]) {
+            if (done[s]) continue;
             sweeps[s]++;
             if (hch[s]) {           // improved, or units still held back by the gate
                 if (hch[s] & CHANGED_IMPROVED) anychange_ever = true;
                 if (sweeps[s] >= ctx->max_sweeps)
                     return set_error("start %d did not converge in %lld sweeps", s, ctx->max_sweeps);
             } else {
-                // converged: remove it from the active list (it may already be gone)
+                // converged: remove it from the active list
+                done[s] = 1;
                 int *end = std::remove(ctx->h_active, ctx->h_active + nactive, s);
                 if (end != ctx->h_active + nactive) dropped = true;
                 nactive = (int)(end - ctx->h_active);
