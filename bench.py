@@ -150,7 +150,7 @@ def measure_traffic(args, kernel_patterns):
             cmd = [exe, "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", d, "--",
                    sys.executable, os.path.abspath(__file__), "--child", "--steps", "1", "--warmup", "1",
                    "--no-cpu"] + workload_args(args)
-            r = subprocess.run(cmd, capture_output=True, text=True, timeout=420, env=env, cwd="/tmp")
+            r = subprocess.run(cmd, capture_output=True, text=True, timeout=150, env=env, cwd="/tmp")
             if r.returncode != 0:
                 return None
             total, n = 0.0, 0
