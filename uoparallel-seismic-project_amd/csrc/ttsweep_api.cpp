@@ -108,7 +108,7 @@ struct ttsweep_ctx {
     int tile_epoch = 1;
     int2 *d_tile_list = nullptr;            // due tiles of the launch in flight
     size_t tile_list_cap = 0;
-    int *d_tile_ctrl = nullptr;             // (count, cursor) per launch of a sweep
+    int *d_tile_ctrl = nullptr;             // number of due tiles, one word per launch of a sweep
     size_t tile_ctrl_cap = 0;
     int tile_blocks = 0;                    // persistent grid of the sweep kernel
     int *d_tile_flags = nullptr;            // capacity_starts x activity words (flag_words)
@@ -705,25 +705,26 @@ static int launch_pass(ttsweep_ctx *ctx, int nactive, int nstart, int *d_changed
             HIPCHK(hipStreamSynchronize(ctx->stream));
             if (ctx->d_tile_ctrl) HIPCHK(hipFree(ctx->d_tile_ctrl));
             ctx->d_tile_ctrl = nullptr;
-            HIPCHK(hipMalloc((void **)&ctx->d_tile_ctrl, (size_t)nsteps * 2 * sizeof(int)));
+            HIPCHK(hipMalloc((void **)&ctx->d_tile_ctrl, (size_t)nsteps * sizeof(int)));
             ctx->tile_ctrl_cap = nsteps;
         }
         if (ctx->tile_blocks == 0) {
             hipDeviceProp_t prop;
             HIPCHK(hipGetDeviceProperties(&prop, ctx->device));
-            // as many single-wavefront workgroups as the LDS of the device holds at once
+            // as many single-wavefront workgroups as the device holds at once
 #ifdef TTSWEEP_TILE_WGS_PER_CU
-            const size_t per_cu = TTSWEEP_TILE_WGS_PER_CU;
+            int per_cu = TTSWEEP_TILE_WGS_PER_CU;
 #else
-            const size_t per_cu = std::max<size_t>(1, (size_t)(160 * 1024) / tile_lds_bytes(ctx->tile_R));
+            int per_cu = 1;
+            HIPCHK(tile_sweep_wgs_per_cu(P, &per_cu));
 #endif
-            ctx->tile_blocks = (int)(per_cu * std::max(prop.multiProcessorCount, 1));
+            ctx->tile_blocks = per_cu * std::max(prop.multiProcessorCount, 1);
         }
-        HIPCHK(hipMemsetAsync(ctx->d_tile_ctrl, 0, (size_t)nsteps * 2 * sizeof(int), ctx->stream));
+        HIPCHK(hipMemsetAsync(ctx->d_tile_ctrl, 0, (size_t)nsteps * sizeof(int), ctx->stream));
         for (int D = 0; D < nsteps; D++) {
             P.D = D;
             P.epoch = ++ctx->tile_epoch;
-            HIPCHK(launch_tile_sweep(P, ctx->d_tile_list, ctx->d_tile_ctrl + 2 * D, ctx->tile_blocks, ctx->stream));
+            HIPCHK(launch_tile_sweep(P, ctx->d_tile_list, ctx->d_tile_ctrl + D, ctx->tile_blocks, ctx->stream));
         }
         ctx->stats.launches += nsteps - 1;
     } else {

@@ -72,12 +72,14 @@ hipError_t launch_init_tile_flags(const DevLayout &L, const StartDesc &sd, bool 
 // One call = the tiles of one hyperplane of an ordering sweep (TileSweep): tile_plan_kernel
 // lists the due ones - a tile is relaxed only if one of its 27 neighbours improved since it
 // was last relaxed (StartDesc::tile_flags holds two words per tile) - in `list` (room for
-// NJ * NK * nactive entries) and counts them in ctrl[0]; tile_sweep_kernel (`nblocks`
-// persistent single-wavefront workgroups) drains the list through the cursor ctrl[1].  Both
-// words must be zero before the call.  A sweep = the calls D = 0 .. NI + NJ + NK - 3 in
+// NJ * NK * nactive entries), counts them in ctrl[0] (zero before the call) and adds their
+// relaxations to the starts' work counters; tile_sweep_kernel (`nblocks` persistent
+// single-wavefront workgroups, at most what tile_sweep_wgs_per_cu says the device holds at
+// once) relaxes entries b, b + nblocks, ...  A sweep = the calls D = 0 .. NI + NJ + NK - 3 in
 // stream order.  changed[s] |= 1 when a tile of start s improved: a whole sweep without a
 // change proves convergence.
 size_t tile_lds_bytes(int R);
+hipError_t tile_sweep_wgs_per_cu(const TileSweep &P, int *wgs);
 hipError_t launch_tile_sweep(const TileSweep &P, int2 *list, int *ctrl, int nblocks, hipStream_t st);
 // from_box = false: only the start's tile counts as changed; true: every tile does.
 hipError_t launch_init_tile_state(const DevLayout &L, const StartDesc &sd, bool from_box, hipStream_t st);

@@ -85,6 +85,10 @@ __device__ __forceinline__ T *uni_ptr(T *p)
 // One thread per (active start, J', K'); the tile is due when one of its 27 neighbours
 // (itself included) improved in or after the epoch it was last relaxed in.  Due tiles are
 // stamped with this epoch and appended to `list` (wave-aggregated); ctrl[0] counts them.
+// The planner also keeps the starts' work counters (relaxations, tiles): one pair of atomics
+// per wavefront and start here instead of one per tile in the sweep kernel, where 10^4
+// workgroups adding to the same few words held every tile up (measured: 22 of 60 ms of a
+// full sweep on 1024x1024x512 x 14 starts went to the per-tile counter and cursor atomics).
 __global__ void __launch_bounds__(256)
 tile_plan_kernel(TileSweep P, int2 *__restrict__ list, int *__restrict__ ctrl)
 {
@@ -92,6 +96,7 @@ tile_plan_kernel(TileSweep P, int2 *__restrict__ list, int *__restrict__ ctrl)
     const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
     bool due = false;
     int s = 0, tile = 0;
+    unsigned cells = 0;                     // cells of the tile inside the grid
     if (t < (long long)P.NJ * P.NK * P.nactive) {
         unsigned u = (unsigned)t;
         const int Kp = u % P.NK; u /= P.NK;
@@ -114,6 +119,8 @@ tile_plan_kernel(TileSweep P, int2 *__restrict__ list, int *__restrict__ ctrl)
             }
             due = newest >= relaxed;
             if (due) state[tile].x = P.epoch;
+            cells = (unsigned)(min(TILE_X, P.L.n[0] - I * TILE_X) * min(TILE_Y, P.L.n[1] - J * TILE_Y)
+                               * min(TILE_Z, P.L.n[2] - K * TILE_Z));
         }
     }
     const unsigned long long m = __ballot(due);
@@ -122,6 +129,23 @@ tile_plan_kernel(TileSweep P, int2 *__restrict__ list, int *__restrict__ ctrl)
     if (lane == __builtin_ctzll(m)) base = atomicAdd(&ctrl[0], __popcll(m));
     base = __shfl(base, __builtin_ctzll(m));
     if (due) list[base + __popcll(m & ((1ull << lane) - 1ull))] = make_int2(s, tile);
+    // work counters: the due lanes of one start at a time (a wavefront rarely spans two)
+    unsigned long long rest = m;
+    while (rest) {
+        const int first = __builtin_ctzll(rest);
+        const int s0 = __shfl(s, first);
+        const bool mine = due && s == s0;
+        const unsigned long long mm = __ballot(mine);
+        unsigned sum = mine ? cells : 0u;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+        if (lane == first) {
+            unsigned long long *const work = P.starts[s0].work;
+            atomicAdd(work, (unsigned long long)sum * (unsigned long long)P.nent);
+            atomicAdd(work + 2, (unsigned long long)__popcll(mm));
+        }
+        rest &= ~mm;
+    }
 }
 
 // -DTTSWEEP_TILE_PROFILE: cycle stamps per phase of a tile, summed over all tiles (tuning aid;
@@ -163,7 +187,7 @@ typedef const __attribute__((address_space(4))) TileItem *const_item_ptr;
 // The 6-neighbour star with halo 1, entries in the pull star's order (sorted by offset):
 // image index deltas and everything derived from them are compile-time constants.
 constexpr int SIX_SY = TILE_Y + 2;
-constexpr int SIX_NITER = ((TILE_X + 2) * SIX_SY * TILE_QPR + 63) / 64;
+constexpr int SIX_NSLOTS = (TILE_X + 2) * SIX_SY * TILE_QPR;      // float4 slots of one image
 constexpr int SIX_DEL[6] = {-SIX_SY * TILE_PITCH, -TILE_PITCH, -1, 1, TILE_PITCH, SIX_SY *TILE_PITCH};
 
 // NE: entries relaxed (the star, padded with no-ops); EXACT: some entry is live in one
@@ -171,7 +195,7 @@ constexpr int SIX_DEL[6] = {-SIX_SY * TILE_PITCH, -TILE_PITCH, -1, 1, TILE_PITCH
 // neighbours (SIX_DEL).
 template <int NE, bool EXACT, bool SIX>
 __global__ void __launch_bounds__(64)
-tile_sweep_kernel(TileSweep P, const int2 *__restrict__ list, int *__restrict__ ctrl)
+tile_sweep_kernel(TileSweep P, const int2 *__restrict__ list, const int *__restrict__ ctrl)
 {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int lane = threadIdx.x;
@@ -183,7 +207,7 @@ tile_sweep_kernel(TileSweep P, const int2 *__restrict__ list, int *__restrict__ 
     const int nslots = (TILE_X + 2 * R) * SY * TILE_QPR;
     const int niter = (nslots + 63) >> 6;
     float *vimg = lds;
-    float *timg = lds + niter * 256;            // (a multiple of 1 KiB behind the v image)
+    float *timg = lds + nslots * 4;             // (directly behind the v image)
 
     // per-lane geometry (the same for every tile of the launch)
     const int ip = lane >> 3, jp = lane & 7;
@@ -202,23 +226,26 @@ tile_sweep_kernel(TileSweep P, const int2 *__restrict__ list, int *__restrict__ 
     // (the same for every tile: computed once, kept for the first iterations' worth)
     const int dat = P.sz > 0 ? 1 : -1;
 
-    // Workgroup b starts with entry b; further entries come from the cursor ctrl[1], which
-    // counts from gridDim.x on (a workgroup without a first entry never touches it: hundreds
-    // of idle workgroups hammering one word cost more than a sparse launch's tiles).
-    int next = blockIdx.x;
+    // Workgroup b relaxes entries b, b + gridDim.x, ...: no cursor.  The tiles of a launch cost
+    // about the same, and an atomic per tile on one word - whose answer the wave's vmcnt(0)
+    // below has to wait for, behind every other workgroup's - cost more than the balance was
+    // worth (with the per-tile work counters: 22 of 60 ms of a full sweep).
+#ifdef TTSWEEP_TILE_PROFILE
+    unsigned long long prof_acc[5] = {};
+#endif
     PROF_STAMP(t_begin);
-    while (next < count) {
+    // (everything that selects the tile is kept in scalar registers: the list entry and the
+    // start descriptor then come through the scalar cache and the buffer descriptors need no
+    // waterfall loop)
+    const int nwg = uni((int)gridDim.x), ntodo = uni(count);
+    for (int next = uni((int)blockIdx.x); next < ntodo; next = uni(next + nwg)) {
         const const_item_ptr ip_ = (const_item_ptr)(list + next);
         const int s = ip_->s, tile = ip_->tile;
-        // the index after this one: asked for now, needed when this tile's sweep is done
-        int after = 0;
-        if (lane == 0) after = atomicAdd(&ctrl[1], 1) + (int)gridDim.x;
         PROF_STAMP(t_top);
 
         const const_start_ptr sdp = (const_start_ptr)(P.starts + s);
         float *const T = sdp->T;
         int2 *const state = reinterpret_cast<int2 *>(sdp->tile_flags);
-        unsigned long long *const work = sdp->work;
         const int sa = sdp->sa, sb = sdp->sb, sc = sdp->sc;
         const int K = tile % P.NK, J = (tile / P.NK) % P.NJ, I = tile / (P.NK * P.NJ);
 
@@ -230,9 +257,10 @@ tile_sweep_kernel(TileSweep P, const int2 *__restrict__ list, int *__restrict__ 
         {
             // (the previous tile's LDS writes have retired before the image is overwritten)
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            const tile_rsrc rv = tile_make_rsrc(P.v + g0), rt = tile_make_rsrc(T + g0);
+            const tile_rsrc rv = tile_make_rsrc(uni_ptr(P.v + g0)), rt = tile_make_rsrc(uni_ptr(T + g0));
             for (int it = 0; it < niter; it++) {
-                const int sl = min(it * 64 + lane, nslots - 1);
+                const int sl = it * 64 + lane;
+                if (sl >= nslots) break;        // (last instruction: the lanes past the image stay off)
                 const int row = sl / TILE_QPR, q = sl - row * TILE_QPR;
                 const int ri = row / SY, rj = row - ri * SY;
                 const unsigned off = (unsigned)ri * s0b + (unsigned)rj * s1b + (unsigned)q * 16u;
@@ -271,7 +299,7 @@ tile_sweep_kernel(TileSweep P, const int2 *__restrict__ list, int *__restrict__ 
                 if (SIX) {
                     // one base register, immediate offsets: the image index of the lowest neighbour
                     const float *vb = vimg + (at + SIX_DEL[0]);
-                    const float *tb = vb + SIX_NITER * 256;
+                    const float *tb = vb + SIX_NSLOTS * 4;
                     vc = vb[-SIX_DEL[0]];
                     tc = tb[-SIX_DEL[0]];
 #pragma unroll
@@ -314,16 +342,9 @@ tile_sweep_kernel(TileSweep P, const int2 *__restrict__ list, int *__restrict__ 
             __builtin_amdgcn_wave_barrier();
         }
         PROF_STAMP(t_swept);
-        // the next entry is known by now; taking it here keeps the stores below out of its wait
-        next = uni(after);
 
         // ---- write the tile back if it improved: 64 rows of 8 float4
         const bool any = __ballot(improved) != 0ull;
-        if (lane == 0) {
-            atomicAdd(work, (unsigned long long)(min(TILE_X, L.n[0] - I * TILE_X) * min(TILE_Y, L.n[1] - J * TILE_Y)
-                                                 * z_cells) * (unsigned long long)P.nent);
-            atomicAdd(work + 2, 1ull);
-        }
         if (any) {
             const long long t0 = (long long)(I * TILE_X + L.lo[0]) * L.s0 + (long long)(J * TILE_Y + L.lo[1]) * L.s1
                                + (K * TILE_Z + L.lo[2]);
@@ -344,36 +365,36 @@ tile_sweep_kernel(TileSweep P, const int2 *__restrict__ list, int *__restrict__ 
         // (the image is overwritten by the next tile's loads: every read of it has been
         // consumed; the stores are in flight and read registers only)
 #ifdef TTSWEEP_TILE_PROFILE
-        if (lane == 0) {
+        {   // (summed per workgroup, added to the totals once at its end: per-tile atomics on
+            // a few words would be the very cost being looked for)
             const long long t_end = prof_now();
-            atomicAdd(&g_tile_prof[0], (unsigned long long)(t_issued - t_top));
-            atomicAdd(&g_tile_prof[1], (unsigned long long)(t_landed - t_issued));
-            atomicAdd(&g_tile_prof[2], (unsigned long long)(t_swept - t_landed));
-            atomicAdd(&g_tile_prof[3], (unsigned long long)(t_end - t_swept));
-            atomicAdd(&g_tile_prof[4], 1ull);
+            prof_acc[0] += (unsigned long long)(t_issued - t_top);
+            prof_acc[1] += (unsigned long long)(t_landed - t_issued);
+            prof_acc[2] += (unsigned long long)(t_swept - t_landed);
+            prof_acc[3] += (unsigned long long)(t_end - t_swept);
+            prof_acc[4] += 1ull;
         }
 #endif
     }
 #ifdef TTSWEEP_TILE_PROFILE
-    if (lane == 0) atomicAdd(&g_tile_prof[5], (unsigned long long)(prof_now() - t_begin));
+    if (lane == 0 && prof_acc[4]) {
+        for (int i = 0; i < 5; i++) atomicAdd(&g_tile_prof[i], prof_acc[i]);
+        atomicAdd(&g_tile_prof[5], (unsigned long long)(prof_now() - t_begin));
+    }
 #endif
 }
 
 size_t tile_lds_bytes(int R)
 {
     const int nslots = (TILE_X + 2 * R) * (TILE_Y + 2 * R) * TILE_QPR;
-    return (size_t)2 * ((nslots + 63) / 64) * 1024;
+    return (size_t)2 * nslots * 16;
 }
 
-hipError_t launch_tile_sweep(const TileSweep &P, int2 *list, int *ctrl, int nblocks, hipStream_t st)
+typedef void (*tile_sweep_fn)(TileSweep, const int2 *, const int *);
+
+// The instance that relaxes this star (see tile_sweep_kernel's template parameters).
+static tile_sweep_fn tile_instance(const TileSweep &P)
 {
-    if (P.nactive <= 0) return hipSuccess;
-    if (P.R < 1 || P.R > TILE_MAX_R || P.nent < 1 || P.nent > TILE_MAX_ENT || nblocks < 1) return hipErrorInvalidValue;
-    const long long cand = (long long)P.NJ * P.NK * P.nactive;
-    if (cand > 0x7fffffffLL) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(tile_plan_kernel, dim3((unsigned)((cand + 255) / 256)), dim3(256), 0, st, P, list, ctrl);
-    const size_t lds = tile_lds_bytes(P.R);
-    nblocks = (int)std::min<long long>(nblocks, cand);
     bool exact = false;
     for (int e = 0; e < P.nent; e++) exact |= P.ent[e].flags != (PULL_FWD | PULL_REV);
     // the plain 6-neighbour star (entries in the pull star's sorted order) has its own instance
@@ -381,13 +402,42 @@ hipError_t launch_tile_sweep(const TileSweep &P, int2 *list, int *ctrl, int nblo
     bool is_six = P.nent == 6 && P.R == 1 && !exact;
     for (int e = 0; e < 6 && is_six; e++)
         is_six = P.ent[e].da == six[e][0] && P.ent[e].db == six[e][1] && P.ent[e].dc == six[e][2];
-#define TILE_LAUNCH(NE, EX, SIX) \
-    hipLaunchKernelGGL((tile_sweep_kernel<NE, EX, SIX>), dim3((unsigned)nblocks), dim3(64), lds, st, P, list, ctrl)
-    if (is_six) TILE_LAUNCH(6, false, true);
-    else if (P.nent <= 6) { if (exact) TILE_LAUNCH(6, true, false); else TILE_LAUNCH(6, false, false); }
-    else if (P.nent <= 18) { if (exact) TILE_LAUNCH(18, true, false); else TILE_LAUNCH(18, false, false); }
-    else { if (exact) TILE_LAUNCH(TILE_MAX_ENT, true, false); else TILE_LAUNCH(TILE_MAX_ENT, false, false); }
-#undef TILE_LAUNCH
+    if (is_six) return tile_sweep_kernel<6, false, true>;
+    if (P.nent <= 6) return exact ? tile_sweep_kernel<6, true, false> : tile_sweep_kernel<6, false, false>;
+    if (P.nent <= 18) return exact ? tile_sweep_kernel<18, true, false> : tile_sweep_kernel<18, false, false>;
+    return exact ? tile_sweep_kernel<TILE_MAX_ENT, true, false> : tile_sweep_kernel<TILE_MAX_ENT, false, false>;
+}
+
+static bool tile_sweep_ok(const TileSweep &P)
+{
+    return P.R >= 1 && P.R <= TILE_MAX_R && P.nent >= 1 && P.nent <= TILE_MAX_ENT;
+}
+
+hipError_t tile_sweep_wgs_per_cu(const TileSweep &P, int *wgs)
+{
+    // What the device really holds at once (the LDS is allocated in granules: five 32 KiB
+    // images do NOT fit 160 KiB).  The sweep kernel strides the list statically, so a grid
+    // larger than this would run its surplus workgroups, full list shares and all, after the
+    // others have finished.
+    if (!tile_sweep_ok(P)) return hipErrorInvalidValue;
+    int n = 0;
+    const hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, (const void *)tile_instance(P), 64,
+                                                                      tile_lds_bytes(P.R));
+    if (e != hipSuccess) return e;
+    *wgs = std::max(n, 1);
+    return hipSuccess;
+}
+
+hipError_t launch_tile_sweep(const TileSweep &P, int2 *list, int *ctrl, int nblocks, hipStream_t st)
+{
+    if (P.nactive <= 0) return hipSuccess;
+    if (!tile_sweep_ok(P) || nblocks < 1) return hipErrorInvalidValue;
+    const long long cand = (long long)P.NJ * P.NK * P.nactive;
+    if (cand > 0x7fffffffLL) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(tile_plan_kernel, dim3((unsigned)((cand + 255) / 256)), dim3(256), 0, st, P, list, ctrl);
+    nblocks = (int)std::min<long long>(nblocks, cand);
+    hipLaunchKernelGGL(tile_instance(P), dim3((unsigned)nblocks), dim3(64), tile_lds_bytes(P.R), st, P,
+                       (const int2 *)list, (const int *)ctrl);
     return hipGetLastError();
 }
 
