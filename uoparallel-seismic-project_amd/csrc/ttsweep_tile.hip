@@ -187,7 +187,6 @@ typedef const __attribute__((address_space(4))) TileItem *const_item_ptr;
 // The 6-neighbour star with halo 1, entries in the pull star's order (sorted by offset):
 // image index deltas and everything derived from them are compile-time constants.
 constexpr int SIX_SY = TILE_Y + 2;
-constexpr int SIX_NSLOTS = (TILE_X + 2) * SIX_SY * TILE_QPR;      // float4 slots of one image
 constexpr int SIX_DEL[6] = {-SIX_SY * TILE_PITCH, -TILE_PITCH, -1, 1, TILE_PITCH, SIX_SY *TILE_PITCH};
 
 // NE: entries relaxed (the star, padded with no-ops); EXACT: some entry is live in one
@@ -293,28 +292,74 @@ tile_sweep_kernel(TileSweep P, const int2 *__restrict__ list, const int *__restr
         bool improved = false;
         int kp = -ip - jp;
         int at = row0 + (P.sz > 0 ? kp : TILE_Z - 1 - kp);
+        if constexpr (SIX) {
+            // Software-pipelined: of a cell's 14 inputs only the travel times of the x- and
+            // y-upwind neighbours were written in the previous step (by other lanes); the
+            // z-upwind one is this lane's own previous result (a register), the downwind ones
+            // and all velocities cannot change before this lane is past them.  So each step
+            // reads just those two values behind the previous step's writes, then - while they
+            // are on their way - everything the NEXT cell needs that is already final, and the
+            // six delays of the current cell come from values that arrived a step ago: the
+            // dependent chain of a step is one LDS round trip plus three vector instructions
+            // instead of a round trip plus the whole relaxation (17 k -> 8 k cycles per tile).
+            // Lanes outside their 32 steps run the same instructions on in-image addresses and
+            // store nothing.
+            const int exu = P.sx > 0 ? 0 : 5, eyu = P.sy > 0 ? 1 : 4, ezu = P.sz > 0 ? 2 : 3;
+            const int dxu = SIX_DEL[exu], dxd = SIX_DEL[5 - exu], dyu = SIX_DEL[eyu], dyd = SIX_DEL[5 - eyu];
+            float hxu = P.ent[exu].h, hxd = P.ent[5 - exu].h, hyu = P.ent[eyu].h, hyd = P.ent[5 - eyu].h,
+                  hzu = P.ent[ezu].h, hzd = P.ent[5 - ezu].h;
+            // (opaque copies in vector registers: otherwise the six lengths are re-read from
+            // the kernel arguments in every step)
+            asm volatile("" : "+v"(hxu), "+v"(hxd), "+v"(hyu), "+v"(hyd), "+v"(hzu), "+v"(hzd));
+            float vc = vimg[at], tc = timg[at];
+            float vzu = vimg[at - dat], tzu = timg[at - dat];
+            float vxu = vimg[at + dxu], vyu = vimg[at + dyu], vxd = vimg[at + dxd], vyd = vimg[at + dyd],
+                  vzd = vimg[at + dat];
+            float txd = timg[at + dxd], tyd = timg[at + dyd], tzd = timg[at + dat];
+#pragma unroll 2
+            for (int d = 0; d < TILE_X + TILE_Y + TILE_Z - 2; d++, kp++, at += dat) {
+                // written in the previous step: asked for first
+                float txu = timg[at + dxu], tyu = timg[at + dyu];
+                __builtin_amdgcn_sched_barrier(0);
+                // final already, wanted by the next cell
+                const int an = at + dat;
+                const float n_vxu = vimg[an + dxu], n_vyu = vimg[an + dyu], n_vxd = vimg[an + dxd],
+                            n_vyd = vimg[an + dyd], n_vzd = vimg[an + dat];
+                const float n_txd = timg[an + dxd], n_tyd = timg[an + dyd], n_tzd = timg[an + dat];
+                __builtin_amdgcn_sched_barrier(0);
+                // this cell: delays and the candidates that do not wait
+                const float cxd = hxd * (vc + vxd) + txd, cyd = hyd * (vc + vyd) + tyd, czd = hzd * (vc + vzd) + tzd;
+                const float czu = hzu * (vc + vzu) + tzu;
+                const float lxu = hxu * (vc + vxu), lyu = hyu * (vc + vyu);
+                float best = fminf(fminf(tc, czu), fminf(fminf(cxd, cyd), czd));
+                asm volatile("" : "+v"(best), "+v"(txu), "+v"(tyu));       // (all lanes, before the two arrive)
+                best = fminf(best, fminf(lxu + txu, lyu + tyu));
+                const bool mine = (unsigned)(kp - klo) < span;
+                best = mine ? best : tc;
+                asm volatile("" : "+v"(best));      // (computed by every lane: no branch around the loads above)
+                if (best < tc) {
+                    timg[at] = best;
+                    improved = true;
+                }
+                // roll on to the next cell of the column
+                tzu = best;
+                vzu = vc;
+                vc = vzd; tc = tzd;
+                vxu = n_vxu; vyu = n_vyu; vxd = n_vxd; vyd = n_vyd; vzd = n_vzd;
+                txd = n_txd; tyd = n_tyd; tzd = n_tzd;
+                // the next step reads what this one wrote (other lanes, same wavefront: LDS
+                // operations of a wavefront execute in order; keep the compiler from moving them)
+                __builtin_amdgcn_wave_barrier();
+            }
+        } else
         for (int d = 0; d < TILE_X + TILE_Y + TILE_Z - 2; d++, kp++, at += dat) {
             if ((unsigned)(kp - klo) < span) {
-                float vc, tc, vo[NE], to[NE];
-                if (SIX) {
-                    // one base register, immediate offsets: the image index of the lowest neighbour
-                    const float *vb = vimg + (at + SIX_DEL[0]);
-                    const float *tb = vb + SIX_NSLOTS * 4;
-                    vc = vb[-SIX_DEL[0]];
-                    tc = tb[-SIX_DEL[0]];
+                float vo[NE], to[NE];
+                const float vc = vimg[at], tc = timg[at];
 #pragma unroll
-                    for (int e = 0; e < NE; e++) {
-                        vo[e] = vb[SIX_DEL[e] - SIX_DEL[0]];
-                        to[e] = tb[SIX_DEL[e] - SIX_DEL[0]];
-                    }
-                } else {
-                    vc = vimg[at];
-                    tc = timg[at];
-#pragma unroll
-                    for (int e = 0; e < NE; e++) {      // all neighbour reads in flight before the first use
-                        vo[e] = vimg[at + del[e]];
-                        to[e] = timg[at + del[e]];
-                    }
+                for (int e = 0; e < NE; e++) {      // all neighbour reads in flight before the first use
+                    vo[e] = vimg[at + del[e]];
+                    to[e] = timg[at + del[e]];
                 }
                 float best = tc;
 #pragma unroll
