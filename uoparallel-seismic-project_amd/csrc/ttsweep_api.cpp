@@ -1104,6 +1104,18 @@ static int solve_device_body(ttsweep_ctx *ctx, int nstart, const ttsweep_start *
                     un - trace_prev_un, us);
             trace_prev = tot;
             trace_prev_un = un;
+            if (ctx->kernel == TTSWEEP_KERNEL_TILE && ctx->d_tile_ctrl) {      // due tiles per launch of the sweep
+                std::vector<int> cnt(ctx->tile_ctrl_cap);
+                HIPCHK(hipMemcpy(cnt.data(), ctx->d_tile_ctrl, cnt.size() * sizeof(int), hipMemcpyDeviceToHost));
+                long long empty = 0, small = 0, big = 0, tiles_small = 0, tiles_big = 0;
+                for (int c : cnt) {
+                    if (c == 0) empty++;
+                    else if (c < ctx->tile_blocks) { small++; tiles_small += c; }
+                    else { big++; tiles_big += c; }
+                }
+                fprintf(stderr, "   launches: %lld empty, %lld below one round (%lld tiles), %lld larger (%lld tiles)\n",
+                        empty, small, tiles_small, big, tiles_big);
+            }
         }
         bool dropped = false;
         for (int s : snapshot[slot]) {

@@ -189,6 +189,93 @@ typedef const __attribute__((address_space(4))) TileItem *const_item_ptr;
 constexpr int SIX_SY = TILE_Y + 2;
 constexpr int SIX_DEL[6] = {-SIX_SY * TILE_PITCH, -TILE_PITCH, -1, 1, TILE_PITCH, SIX_SY *TILE_PITCH};
 
+// The systolic sweep of the plain 6-neighbour star over the staged tile.  Lane (i', j') owns
+// the z-column (i', j') and relaxes TWO cells per step, k' = 2m and 2m + 1 with
+// m = d - i' - j' (30 steps for 8 x 8 x 32): the first cell's z-upwind neighbour is the lane's
+// own previous result, the second's is the first.  Software-pipelined: of a pair's inputs only
+// the travel times of its four lateral neighbour pairs can have been written in the previous
+// step (by other lanes; two of them really were, which two depends on the ordering); the
+// z-downwind values and all velocities cannot change before this lane is past them.  So a
+// step reads just those four pairs behind the previous step's writes, then - while they are on
+// their way - what the NEXT pair needs that is final already; the delays of the current pair
+// come from values that arrived a step ago.  The dependent chain of a step is one LDS round
+// trip plus about ten vector instructions, for two cells.  A step is also short in
+// instructions: one address register (every input is a compile-time offset from it: ZPOS is
+// the direction along z), 64-bit LDS accesses (a pair is 8-byte aligned), and the lateral
+// relaxations as packed operations over the pair.  Lanes outside their 16 steps run the same
+// instructions on in-image addresses and store nothing.  Entries in the pull star's order:
+// x-, y-, z-, z+, y+, x+.
+typedef float tile_f2 __attribute__((ext_vector_type(2)));
+
+template <bool ZPOS>
+__device__ __forceinline__ bool six_sweep(float *vimg, int t_off, int row0, int ij, int klo, unsigned span,
+                                          const TileSweep &P)
+{
+    static_assert(TILE_Z % 2 == 0 && TILE_ZF % 2 == 0 && TILE_PITCH % 2 == 0, "pairs must be 8-byte aligned");
+    constexpr int DP = ZPOS ? 2 : -2, DX = SIX_SY * TILE_PITCH, DY = TILE_PITCH;
+    constexpr int C = DX + 4;               // index of the current pair from the base below (every index >= 0)
+    // (opaque copies in vector registers: otherwise the lengths are re-read from the kernel
+    // arguments in every step)
+    float hxm = P.ent[0].h, hxp = P.ent[5].h, hym = P.ent[1].h, hyp = P.ent[4].h,
+          hzu = P.ent[ZPOS ? 2 : 3].h, hzd = P.ent[ZPOS ? 3 : 2].h;
+    asm volatile("" : "+v"(hxm), "+v"(hxp), "+v"(hym), "+v"(hyp), "+v"(hzu), "+v"(hzd));
+    const tile_f2 hxm2 = {hxm, hxm}, hxp2 = {hxp, hxp}, hym2 = {hym, hym}, hyp2 = {hyp, hyp};
+    // pairs in memory order (lower z first); FIRST / SECOND: the cell relaxed first / second
+#define FIRST(p) (ZPOS ? (p).x : (p).y)
+#define SECOND(p) (ZPOS ? (p).y : (p).x)
+#define LD2(i) (*reinterpret_cast<const tile_f2 *>(vb + (i)))
+    int m = -ij;                            // pair of this step: k' = 2m, 2m + 1
+    const float *vb = vimg + (row0 + (ZPOS ? 2 * m : TILE_Z - 2 - 2 * m) - C);      // the one address: advances by DP per step
+    tile_f2 vp = LD2(C), tp = LD2(t_off + C);                 // own pair
+    tile_f2 nv = LD2(C + DP), nt = LD2(t_off + C + DP);       // own next pair
+    float vzu = SECOND(LD2(C - DP)), tzu = SECOND(LD2(t_off + C - DP));     // own previous cell
+    tile_f2 vxm = LD2(C - DX), vxp = LD2(C + DX), vym = LD2(C - DY), vyp = LD2(C + DY);
+    bool improved = false;
+#pragma unroll 2
+    for (int d = 0; d < TILE_X + TILE_Y + TILE_Z / 2 - 2; d++, m++, vb += DP) {
+        // possibly written in the previous step: asked for first
+        tile_f2 txm = LD2(t_off + C - DX), txp = LD2(t_off + C + DX), tym = LD2(t_off + C - DY), typ = LD2(t_off + C + DY);
+        __builtin_amdgcn_sched_barrier(0);
+        // final already, wanted by the next pair (and the pair after it along the column)
+        const tile_f2 n_vxm = LD2(C + DP - DX), n_vxp = LD2(C + DP + DX), n_vym = LD2(C + DP - DY), n_vyp = LD2(C + DP + DY);
+        const tile_f2 n_nv = LD2(C + 2 * DP), n_nt = LD2(t_off + C + 2 * DP);
+        __builtin_amdgcn_sched_barrier(0);
+        // this pair: lateral delays (both cells at once), the column's delays and candidates
+        const tile_f2 lxm = hxm2 * (vp + vxm), lxp = hxp2 * (vp + vxp), lym = hym2 * (vp + vym), lyp = hyp2 * (vp + vyp);
+        const float vf = FIRST(vp), vs = SECOND(vp), tf = FIRST(tp), ts = SECOND(tp);
+        const float sfs = vf + vs;
+        const float czu_f = hzu * (vf + vzu) + tzu;             // first cell from its z-upwind neighbour
+        const float czd_f = hzd * sfs + ts;                     // first from second (old value)
+        const float lzu_s = hzu * sfs;                          // second from first (this step's result)
+        const float czd_s = hzd * (vs + FIRST(nv)) + FIRST(nt); // second from the next pair's first
+        float pre_f = fminf(tf, fminf(czu_f, czd_f)), pre_s = fminf(ts, czd_s);
+        const bool mine_f = (unsigned)(2 * m - klo) < span, mine_s = (unsigned)(2 * m + 1 - klo) < span;
+        asm volatile("" : "+v"(pre_f), "+v"(pre_s), "+v"(txm), "+v"(txp), "+v"(tym), "+v"(typ));  // (all lanes, before the four arrive)
+        const tile_f2 cxm = lxm + txm, cxp = lxp + txp, cym = lym + tym, cyp = lyp + typ;
+        pre_s = fminf(fminf(pre_s, fminf(SECOND(cxm), SECOND(cxp))), fminf(SECOND(cym), SECOND(cyp)));
+        float best_f = fminf(fminf(pre_f, fminf(FIRST(cxm), FIRST(cxp))), fminf(FIRST(cym), FIRST(cyp)));
+        best_f = mine_f ? best_f : tf;
+        float best_s = fminf(pre_s, lzu_s + best_f);
+        best_s = mine_s ? best_s : ts;
+        asm volatile("" : "+v"(best_f), "+v"(best_s));      // (computed by every lane: no branch around the loads above)
+        if (best_f < tf || best_s < ts) {
+            *reinterpret_cast<tile_f2 *>(const_cast<float *>(vb) + t_off + C) = ZPOS ? tile_f2{best_f, best_s} : tile_f2{best_s, best_f};
+            improved = true;
+        }
+        // roll on to the next pair of the column
+        tzu = best_s; vzu = vs;
+        vp = nv; tp = nt; nv = n_nv; nt = n_nt;
+        vxm = n_vxm; vxp = n_vxp; vym = n_vym; vyp = n_vyp;
+        // the next step reads what this one wrote (other lanes, same wavefront: LDS
+        // operations of a wavefront execute in order; keep the compiler from moving them)
+        __builtin_amdgcn_wave_barrier();
+    }
+#undef FIRST
+#undef SECOND
+#undef LD2
+    return improved;
+}
+
 // NE: entries relaxed (the star, padded with no-ops); EXACT: some entry is live in one
 // direction only, i.e. liveness has to be evaluated; SIX: the star is exactly the six axis
 // neighbours (SIX_DEL).
@@ -293,64 +380,8 @@ tile_sweep_kernel(TileSweep P, const int2 *__restrict__ list, const int *__restr
         int kp = -ip - jp;
         int at = row0 + (P.sz > 0 ? kp : TILE_Z - 1 - kp);
         if constexpr (SIX) {
-            // Software-pipelined: of a cell's 14 inputs only the travel times of the x- and
-            // y-upwind neighbours were written in the previous step (by other lanes); the
-            // z-upwind one is this lane's own previous result (a register), the downwind ones
-            // and all velocities cannot change before this lane is past them.  So each step
-            // reads just those two values behind the previous step's writes, then - while they
-            // are on their way - everything the NEXT cell needs that is already final, and the
-            // six delays of the current cell come from values that arrived a step ago: the
-            // dependent chain of a step is one LDS round trip plus three vector instructions
-            // instead of a round trip plus the whole relaxation (17 k -> 8 k cycles per tile).
-            // Lanes outside their 32 steps run the same instructions on in-image addresses and
-            // store nothing.
-            const int exu = P.sx > 0 ? 0 : 5, eyu = P.sy > 0 ? 1 : 4, ezu = P.sz > 0 ? 2 : 3;
-            const int dxu = SIX_DEL[exu], dxd = SIX_DEL[5 - exu], dyu = SIX_DEL[eyu], dyd = SIX_DEL[5 - eyu];
-            float hxu = P.ent[exu].h, hxd = P.ent[5 - exu].h, hyu = P.ent[eyu].h, hyd = P.ent[5 - eyu].h,
-                  hzu = P.ent[ezu].h, hzd = P.ent[5 - ezu].h;
-            // (opaque copies in vector registers: otherwise the six lengths are re-read from
-            // the kernel arguments in every step)
-            asm volatile("" : "+v"(hxu), "+v"(hxd), "+v"(hyu), "+v"(hyd), "+v"(hzu), "+v"(hzd));
-            float vc = vimg[at], tc = timg[at];
-            float vzu = vimg[at - dat], tzu = timg[at - dat];
-            float vxu = vimg[at + dxu], vyu = vimg[at + dyu], vxd = vimg[at + dxd], vyd = vimg[at + dyd],
-                  vzd = vimg[at + dat];
-            float txd = timg[at + dxd], tyd = timg[at + dyd], tzd = timg[at + dat];
-#pragma unroll 2
-            for (int d = 0; d < TILE_X + TILE_Y + TILE_Z - 2; d++, kp++, at += dat) {
-                // written in the previous step: asked for first
-                float txu = timg[at + dxu], tyu = timg[at + dyu];
-                __builtin_amdgcn_sched_barrier(0);
-                // final already, wanted by the next cell
-                const int an = at + dat;
-                const float n_vxu = vimg[an + dxu], n_vyu = vimg[an + dyu], n_vxd = vimg[an + dxd],
-                            n_vyd = vimg[an + dyd], n_vzd = vimg[an + dat];
-                const float n_txd = timg[an + dxd], n_tyd = timg[an + dyd], n_tzd = timg[an + dat];
-                __builtin_amdgcn_sched_barrier(0);
-                // this cell: delays and the candidates that do not wait
-                const float cxd = hxd * (vc + vxd) + txd, cyd = hyd * (vc + vyd) + tyd, czd = hzd * (vc + vzd) + tzd;
-                const float czu = hzu * (vc + vzu) + tzu;
-                const float lxu = hxu * (vc + vxu), lyu = hyu * (vc + vyu);
-                float best = fminf(fminf(tc, czu), fminf(fminf(cxd, cyd), czd));
-                asm volatile("" : "+v"(best), "+v"(txu), "+v"(tyu));       // (all lanes, before the two arrive)
-                best = fminf(best, fminf(lxu + txu, lyu + tyu));
-                const bool mine = (unsigned)(kp - klo) < span;
-                best = mine ? best : tc;
-                asm volatile("" : "+v"(best));      // (computed by every lane: no branch around the loads above)
-                if (best < tc) {
-                    timg[at] = best;
-                    improved = true;
-                }
-                // roll on to the next cell of the column
-                tzu = best;
-                vzu = vc;
-                vc = vzd; tc = tzd;
-                vxu = n_vxu; vyu = n_vyu; vxd = n_vxd; vyd = n_vyd; vzd = n_vzd;
-                txd = n_txd; tyd = n_tyd; tzd = n_tzd;
-                // the next step reads what this one wrote (other lanes, same wavefront: LDS
-                // operations of a wavefront execute in order; keep the compiler from moving them)
-                __builtin_amdgcn_wave_barrier();
-            }
+            improved = P.sz > 0 ? six_sweep<true>(vimg, nslots * 4, row0, ip + jp, klo, span, P)
+                                : six_sweep<false>(vimg, nslots * 4, row0, ip + jp, klo, span, P);
         } else
         for (int d = 0; d < TILE_X + TILE_Y + TILE_Z - 2; d++, kp++, at += dat) {
             if ((unsigned)(kp - klo) < span) {
