@@ -1,0 +1,8 @@
+#!/bin/bash
+cd "$GRAFT_REPO_ROOT"
+for lib in uoparallel-seismic-project_amd/csrc/libttsweep.so gpurun_exp/lo32.so; do
+  echo "== $lib"
+  TTSWEEP_EXPERIMENT_LIB=$lib python -m pytest tests/test_gpu_parity.py -x -q -m gpu -k "tile" 2>&1 | tail -1
+  TTSWEEP_EXPERIMENT_LIB=$lib python tools/exp/one_sweep.py 1024,1024,512 14 2>&1 | tail -1
+  TTSWEEP_EXPERIMENT_LIB=$lib python bench.py --star six --grid 1024,1024,512 --starts 111 --nstarts 14 --steps 2 --warmup 1 --no-traffic --no-host --no-cpu 2>/dev/null | python -c "import sys,json; d=json.loads([l for l in sys.stdin if l.startswith('{\"metric')][0]); print('solve ms', d['ms_per_step'], 'hbm frac', d['roofline']['frac'])"
+done

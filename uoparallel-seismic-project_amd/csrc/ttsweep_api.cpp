@@ -104,7 +104,8 @@ struct ttsweep_ctx {
     double gate_r0 = 0.0;
     // TILE kernel: the star in device axes, halo of the staged image, launch counter
     TileEntry tile_ent[TILE_MAX_ENT];
-    int tile_nent = 0, tile_R = 1;
+    int tile_nent = 0, tile_R = 1, tile_fz = 1;     // entries, max |da|,|db|, max |dc| of the star
+    float *d_vface = nullptr, *d_tface = nullptr;   // z faces of v and of every start's T (TILE layout)
     int tile_epoch = 1;
     int2 *d_tile_list = nullptr;            // due tiles of the launch in flight
     size_t tile_list_cap = 0;
@@ -233,8 +234,8 @@ static void make_layout_strip(ttsweep_ctx *ctx)
 }
 
 // Padded layout for the TILE kernel: identity axis order (z stays the stride-1 axis),
-// whole tiles, halo R along x and y, TILE_ZF cells in front of and behind every row so that
-// the staged rows start on 16-byte boundaries.
+// whole tiles, halo R along x and y, one tile of halo in front of and behind every row so
+// that a tile's rows are whole 128-byte lines (the allocation is at least that aligned).
 static void make_layout_tile(ttsweep_ctx *ctx)
 {
     DevLayout &L = ctx->L;
@@ -246,11 +247,13 @@ static void make_layout_tile(ttsweep_ctx *ctx)
         r[1] = std::max(r[1], std::abs(e.dj));
     }
     ctx->tile_R = std::max(r[0], r[1]);
+    ctx->tile_fz = 1;
+    for (const auto &e : ctx->pull) ctx->tile_fz = std::max(ctx->tile_fz, std::abs(e.dk));
     for (int d = 0; d < 3; d++) {
         L.perm[d] = d;
         L.n[d] = n[d];
         L.un[d] = n[d];
-        L.lo[d] = d < 2 ? ctx->tile_R : TILE_ZF;
+        L.lo[d] = d < 2 ? ctx->tile_R : TILE_Z;         // (a whole tile in front: tile rows are whole lines)
         L.p[d] = tile_count(n[d], t[d]) * t[d] + 2 * L.lo[d];
     }
 #ifdef TTSWEEP_TILE_ZPAD        // experiment: row / plane pitch against memory-channel aliasing
@@ -508,6 +511,8 @@ static int ensure_capacity(ttsweep_ctx *ctx, int nstart)
     if (ctx->d_tile_flags) HIPCHK(hipFree(ctx->d_tile_flags));
     if (ctx->d_work) HIPCHK(hipFree(ctx->d_work));
     if (ctx->h_work) HIPCHK(hipHostFree(ctx->h_work));
+    if (ctx->d_tface) HIPCHK(hipFree(ctx->d_tface));
+    ctx->d_tface = nullptr;
     ctx->d_tile_flags = nullptr; ctx->d_work = nullptr; ctx->h_work = nullptr;
     ctx->d_T = nullptr; ctx->d_starts = nullptr; ctx->d_active = nullptr; ctx->d_changed = nullptr;
     ctx->h_starts = nullptr; ctx->h_active = nullptr; ctx->h_changed = nullptr;
@@ -523,6 +528,9 @@ static int ensure_capacity(ttsweep_ctx *ctx, int nstart)
                      (size_t)nstart * flag_words(ctx->L) * sizeof(int)));
     HIPCHK(hipMalloc((void **)&ctx->d_work, 3 * nstart * sizeof(unsigned long long)));
     HIPCHK(hipHostMalloc((void **)&ctx->h_work, 3 * nstart * sizeof(unsigned long long)));
+    if (ctx->kernel == TTSWEEP_KERNEL_TILE)
+        HIPCHK(hipMalloc((void **)&ctx->d_tface,
+                         (size_t)nstart * tile_face_cells(ctx->L, ctx->tile_fz) * sizeof(float)));
     ctx->capacity_starts = nstart;
     return 0;
 }
@@ -691,6 +699,10 @@ static int launch_pass(ttsweep_ctx *ctx, int nactive, int nstart, int *d_changed
         P.sy = (o & 2) ? -1 : 1;
         P.sz = (o & 4) ? -1 : 1;
         P.nent = ctx->tile_nent;
+        P.fz = ctx->tile_fz;
+        P.vface = ctx->d_vface;
+        P.tface = ctx->d_tface;
+        P.face_cells = tile_face_cells(ctx->L, ctx->tile_fz);
         for (int e = 0; e < TILE_MAX_ENT; e++) P.ent[e] = ctx->tile_ent[e];
         const int nsteps = P.NI + P.NJ + P.NK - 2;
         const size_t need_list = (size_t)P.NJ * P.NK * nactive;
@@ -847,6 +859,8 @@ void ttsweep_destroy(ttsweep_ctx *ctx)
     (void)hipFree(ctx->d_unitq_ctrl);
     (void)hipFree(ctx->d_work);
     (void)hipFree(ctx->d_tile_list);
+    (void)hipFree(ctx->d_vface);
+    (void)hipFree(ctx->d_tface);
     (void)hipFree(ctx->d_tile_ctrl);
     if (ctx->h_work) (void)hipHostFree(ctx->h_work);
     if (ctx->h_starts) (void)hipHostFree(ctx->h_starts);
@@ -879,6 +893,8 @@ int ttsweep_set_option(ttsweep_ctx *ctx, int key, long long value)
         make_layout(ctx);
         HIPCHK(hipFree(ctx->d_v));
         ctx->d_v = nullptr;
+        if (ctx->d_vface) HIPCHK(hipFree(ctx->d_vface));
+        ctx->d_vface = nullptr;
         ctx->have_v = false;
         if (ctx->d_T) HIPCHK(hipFree(ctx->d_T));
         ctx->d_T = nullptr;
@@ -925,6 +941,11 @@ int ttsweep_set_velocity_device(ttsweep_ctx *ctx, const float *v_dev)
     HIPCHK(launch_count_bad_velocity(v_dev, n, d_bad, ctx->stream));
     HIPCHK(hipMemcpyAsync(&h_bad, d_bad, sizeof h_bad, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(launch_pack(ctx->L, v_dev, ctx->d_v, 0.0f, ctx->stream));
+    if (ctx->kernel == TTSWEEP_KERNEL_TILE) {
+        if (!ctx->d_vface)
+            HIPCHK(hipMalloc((void **)&ctx->d_vface, (size_t)tile_face_cells(ctx->L, ctx->tile_fz) * sizeof(float)));
+        HIPCHK(launch_build_tile_faces(ctx->L, ctx->d_v, ctx->d_vface, ctx->tile_fz, ctx->stream));
+    }
     HIPCHK(hipStreamSynchronize(ctx->stream));
     if (h_bad) {
         ctx->have_v = false;
@@ -1017,8 +1038,11 @@ static int solve_device_body(ttsweep_ctx *ctx, int nstart, const ttsweep_start *
         else HIPCHK(launch_pack(L, tt_dev[s], sd.T, INFINITY, ctx->stream));
         if (ctx->kernel == TTSWEEP_KERNEL_STRIP)
             HIPCHK(launch_init_tile_flags(L, sd, /*from_box=*/!init, ctx->stream));
-        if (ctx->kernel == TTSWEEP_KERNEL_TILE)
+        if (ctx->kernel == TTSWEEP_KERNEL_TILE) {
             HIPCHK(launch_init_tile_state(L, sd, /*from_box=*/!init, ctx->stream));
+            HIPCHK(launch_build_tile_faces(L, sd.T, ctx->d_tface + (size_t)s * tile_face_cells(L, ctx->tile_fz),
+                                           ctx->tile_fz, ctx->stream));
+        }
         ctx->h_active[s] = s;
     }
     if (ctx->kernel == TTSWEEP_KERNEL_STRIP) {

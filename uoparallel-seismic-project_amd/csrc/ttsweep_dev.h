@@ -153,6 +153,24 @@ constexpr int TILE_MAX_ENT = 26;                        // pull entries (the 26-
 
 __host__ __device__ inline int tile_count(int n, int t) { return (n + t - 1) / t; }
 
+// z faces (TILE layout): tile rows are whole 128-byte lines of the volumes (the z halo in front
+// of the interior is a whole tile wide), so the FZ = max |dc| cells a tile needs beyond either
+// end of its rows would cost two more lines per row.  They come from compact copies instead:
+// for every tile boundary kb = 0 .. NK along c, side 0 holds the FZ cells below it
+// (c = TILE_Z kb - FZ + layer), side 1 the FZ cells above it (c = TILE_Z kb + layer), for every
+// padded (a, b) - a few lines per tile instead of 2 x 100.  The velocity faces are written
+// once, the travel-time faces of a start when its box is initialised and by every tile that
+// improves (its own first and last FZ layers).
+__host__ __device__ inline long long tile_face_index(const DevLayout &L, int fz, int kb, int side, int layer,
+                                                     int pa, int pb)
+{
+    return ((((long long)kb * 2 + side) * fz + layer) * L.p[0] + pa) * L.p[1] + pb;
+}
+__host__ __device__ inline long long tile_face_cells(const DevLayout &L, int fz)
+{
+    return (long long)(tile_count(L.n[2], TILE_Z) + 1) * 2 * fz * L.p[0] * L.p[1];
+}
+
 struct TileEntry {
     int da, db, dc;     // offset in device axes
     float h;            // d / 2
@@ -174,6 +192,10 @@ struct TileSweep {
     int D;                  // hyperplane: tiles with I' + J' + K' == D (coordinates in sweep direction)
     int epoch;              // launch number within the solve (>= 2)
     int nent;               // pull entries in use; ent[nent..] are no-ops (h = 0 onto the cell itself)
+    int fz;                 // max |dc|: layers per z face
+    const float *vface;     // velocity faces
+    float *tface;           // travel-time faces of start 0; start s: + s * face_cells
+    long long face_cells;
     TileEntry ent[TILE_MAX_ENT];
 };
 

@@ -77,20 +77,63 @@ init_tt_kernel(long long cells, float *__restrict__ padded, long long sidx)
     padded[idx] = (idx == sidx) ? 0.0f : __builtin_inff();
 }
 
+// The same copies, four cells per thread, for layouts whose stride-1 axis is the user's z
+// and whose rows are 16-byte aligned on both sides (the usual case): whole float4 of a padded
+// row lie either inside or outside the interior.
+__global__ void __launch_bounds__(256)
+pack_rows_kernel(DevLayout L, const float *__restrict__ user, float *__restrict__ padded, float halo_value)
+{
+    const unsigned idx = blockIdx.x * 256u + threadIdx.x;       // float4 of the padded volume
+    const unsigned qrow = (unsigned)(L.s1 >> 2), qplane = (unsigned)(L.s0 >> 2);
+    if (idx >= (unsigned)(L.cells >> 2)) return;
+    const unsigned pa = idx / qplane, rem = idx - pa * qplane, pb = rem / qrow, pq = rem - pb * qrow;
+    const int a = (int)pa - L.lo[0], b = (int)pb - L.lo[1], c = (int)(4 * pq) - L.lo[2];
+    float4 val = make_float4(halo_value, halo_value, halo_value, halo_value);
+    if (interior(L, a, b, c)) val = *reinterpret_cast<const float4 *>(user + user_index(L, a, b, c));
+    reinterpret_cast<float4 *>(padded)[idx] = val;
+}
+
+__global__ void __launch_bounds__(256)
+unpack_rows_kernel(DevLayout L, const float *__restrict__ padded, float *__restrict__ user)
+{
+    const unsigned idx = blockIdx.x * 256u + threadIdx.x;       // float4 of the interior
+    const unsigned nq = (unsigned)L.n[2] >> 2;
+    if (idx >= (unsigned)L.n[0] * (unsigned)L.n[1] * nq) return;
+    const unsigned row = idx / nq, q = idx - row * nq;
+    const int a = (int)(row / (unsigned)L.n[1]), b = (int)(row - (unsigned)a * (unsigned)L.n[1]), c = (int)(4 * q);
+    *reinterpret_cast<float4 *>(user + user_index(L, a, b, c)) =
+        *reinterpret_cast<const float4 *>(padded + dev_index(L, a, b, c));
+}
+
 static inline unsigned blocks_for(long long n, int per) { return (unsigned)((n + per - 1) / per); }
+
+static bool rows_vectorisable(const DevLayout &L, const void *user, const void *padded)
+{
+    return L.perm[2] == 2 && L.n[2] % 4 == 0 && L.lo[2] % 4 == 0 && L.s0 % 4 == 0 && L.s1 % 4 == 0
+        && L.cells % 4 == 0 && L.cells / 4 < 0x7fffffffLL
+        && (reinterpret_cast<uintptr_t>(user) & 15u) == 0 && (reinterpret_cast<uintptr_t>(padded) & 15u) == 0;
+}
 
 hipError_t launch_pack(const DevLayout &L, const float *user, float *padded,
                        float halo_value, hipStream_t st)
 {
-    hipLaunchKernelGGL(pack_kernel, dim3(blocks_for(L.cells, 256)), dim3(256), 0, st,
-                       L, user, padded, halo_value);
+    if (rows_vectorisable(L, user, padded))
+        hipLaunchKernelGGL(pack_rows_kernel, dim3(blocks_for(L.cells / 4, 256)), dim3(256), 0, st,
+                           L, user, padded, halo_value);
+    else
+        hipLaunchKernelGGL(pack_kernel, dim3(blocks_for(L.cells, 256)), dim3(256), 0, st,
+                           L, user, padded, halo_value);
     return hipGetLastError();
 }
 
 hipError_t launch_unpack(const DevLayout &L, const float *padded, float *user, hipStream_t st)
 {
-    hipLaunchKernelGGL(unpack_kernel, dim3(blocks_for(L.cells, 256)), dim3(256), 0, st,
-                       L, padded, user);
+    if (rows_vectorisable(L, user, padded))
+        hipLaunchKernelGGL(unpack_rows_kernel, dim3(blocks_for((long long)L.n[0] * L.n[1] * (L.n[2] / 4), 256)),
+                           dim3(256), 0, st, L, padded, user);
+    else
+        hipLaunchKernelGGL(unpack_kernel, dim3(blocks_for(L.cells, 256)), dim3(256), 0, st,
+                           L, padded, user);
     return hipGetLastError();
 }
 

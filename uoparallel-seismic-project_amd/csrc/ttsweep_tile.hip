@@ -66,6 +66,29 @@ hipError_t launch_init_tile_state(const DevLayout &L, const StartDesc &sd, bool 
     return hipGetLastError();
 }
 
+// The z faces of a padded volume (tile_face_index): one thread per face cell.
+__global__ void __launch_bounds__(256)
+build_tile_faces_kernel(DevLayout L, const float *__restrict__ padded, float *__restrict__ faces, int fz, long long n)
+{
+    const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (t >= n) return;
+    const int pb = (int)(t % L.p[1]);
+    long long u = t / L.p[1];
+    const int pa = (int)(u % L.p[0]);  u /= L.p[0];
+    const int layer = (int)(u % fz);   u /= fz;
+    const int side = (int)(u & 1), kb = (int)(u >> 1);
+    const int c = TILE_Z * kb + (side ? layer : layer - fz);        // interior coordinate; the halo holds the rest
+    faces[t] = padded[(long long)pa * L.s0 + (long long)pb * L.s1 + (c + L.lo[2])];
+}
+
+hipError_t launch_build_tile_faces(const DevLayout &L, const float *padded, float *faces, int fz, hipStream_t st)
+{
+    if (fz < 1 || fz > TILE_ZF || L.lo[2] < fz) return hipErrorInvalidValue;
+    const long long n = tile_face_cells(L, fz);
+    hipLaunchKernelGGL(build_tile_faces_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, L, padded, faces, fz, n);
+    return hipGetLastError();
+}
+
 // A value the compiler can treat as wave-uniform (it is: every lane holds the same bits).
 // Without this the buffer descriptors below sit in vector registers and every LDS-DMA
 // instruction is wrapped in a "waterfall" loop.
@@ -336,10 +359,20 @@ tile_sweep_kernel(TileSweep P, const int2 *__restrict__ list, const int *__restr
         const int K = tile % P.NK, J = (tile / P.NK) % P.NJ, I = tile / (P.NK * P.NJ);
 
         // ---- stage the tile and its halo: rows (x - R .. x + 7 + R, y - R .. y + 7 + R), each
-        // 10 float4 wide (z0 - 4 .. z0 + 35), by LDS-DMA: slot = row * 10 + float4, the image is
-        // linear in slot order, so one wave-instruction fills 1 KiB with 64 arbitrary float4
+        // 10 float4 wide, by LDS-DMA: slot = row * 10 + float4, the image is linear in slot
+        // order, so one wave-instruction fills 1 KiB with 64 arbitrary float4.  The interior
+        // of a row is one whole 128-byte line of the volume; the first and the last float4 of
+        // an image row (the z halo) are fetched from that same line (any values: no further
+        // line is touched) and their cells next to the interior are then overwritten with the
+        // z faces, which arrive in registers meanwhile.
         const long long g0 = (long long)(I * TILE_X + L.lo[0] - R) * L.s0
                            + (long long)(J * TILE_Y + L.lo[1] - R) * L.s1 + (K * TILE_Z + L.lo[2] - TILE_ZF);
+        const int FZ = SIX ? 1 : P.fz;
+        const int nface = (TILE_X + 2 * R) * SY * 2 * FZ;           // face cells around this tile
+        const float *const tface = P.tface + (long long)s * P.face_cells;
+        constexpr int NFI = SIX ? ((TILE_X + 2) * (TILE_Y + 2) * 2 + 63) / 64
+                                : ((TILE_X + 2 * TILE_MAX_R) * (TILE_Y + 2 * TILE_MAX_R) * 2 * TILE_ZF + 63) / 64;
+        float fv[NFI], ft[NFI];
         {
             // (the previous tile's LDS writes have retired before the image is overwritten)
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -347,13 +380,27 @@ tile_sweep_kernel(TileSweep P, const int2 *__restrict__ list, const int *__restr
             for (int it = 0; it < niter; it++) {
                 const int sl = it * 64 + lane;
                 if (sl >= nslots) break;        // (last instruction: the lanes past the image stay off)
-                const int row = sl / TILE_QPR, q = sl - row * TILE_QPR;
+                const int row = sl / TILE_QPR, q = min(max(sl - row * TILE_QPR, 1), TILE_QPR - 2);
                 const int ri = row / SY, rj = row - ri * SY;
                 const unsigned off = (unsigned)ri * s0b + (unsigned)rj * s1b + (unsigned)q * 16u;
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rv, (__attribute__((address_space(3))) void *)(vimg + it * 256),
                                                          16, (int)off, 0, 0, 0);
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rt, (__attribute__((address_space(3))) void *)(timg + it * 256),
                                                          16, (int)off, 0, 0, 0);
+            }
+#pragma unroll
+            for (int it = 0; it < NFI; it++) {
+                const int f = it * 64 + lane;
+                fv[it] = 0.0f;
+                ft[it] = 0.0f;
+                if (f < nface) {
+                    const int row = f / (2 * FZ), rest = f - row * (2 * FZ), side = rest / FZ, layer = rest - side * FZ;
+                    const int ri = row / SY, rj = row - ri * SY;
+                    // below the tile: boundary K, its lower side; above: boundary K + 1, its upper side
+                    const long long fi = tile_face_index(L, FZ, K + side, side, layer, I * TILE_X + ri, J * TILE_Y + rj);
+                    fv[it] = P.vface[fi];
+                    ft[it] = tface[fi];
+                }
             }
         }
 
@@ -373,6 +420,17 @@ tile_sweep_kernel(TileSweep P, const int2 *__restrict__ list, const int *__restr
 
         PROF_STAMP(t_issued);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // the image has landed (one wave: no barrier)
+#pragma unroll
+        for (int it = 0; it < NFI; it++) {                  // the z faces into the halo cells of the rows
+            const int f = it * 64 + lane;
+            if (f < nface) {
+                const int row = f / (2 * FZ), rest = f - row * (2 * FZ), side = rest / FZ, layer = rest - side * FZ;
+                const int pos = row * TILE_PITCH + (side ? TILE_ZF + TILE_Z + layer : TILE_ZF - FZ + layer);
+                vimg[pos] = fv[it];
+                timg[pos] = ft[it];
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
         PROF_STAMP(t_landed);
 
         // ---- the systolic sweep: lane (i', j') relaxes k' = d - i' - j' in step d
@@ -433,6 +491,15 @@ tile_sweep_kernel(TileSweep P, const int2 *__restrict__ list, const int *__restr
                     timg + ((ri + R) * SY + (rj + R)) * TILE_PITCH + TILE_ZF + 4 * q);
                 *reinterpret_cast<float4 *>(T + t0 + (long long)ri * L.s0 + (long long)rj * L.s1 + 4 * q) = val;
             }
+            // this column's first and last FZ cells into the faces of the tile's two boundaries
+            {
+                float *const tf = const_cast<float *>(tface);
+                const int pa = I * TILE_X + R + ci, pb = J * TILE_Y + R + cj;
+                for (int l = 0; l < FZ; l++) {
+                    tf[tile_face_index(L, FZ, K, 1, l, pa, pb)] = timg[row0 + l];
+                    tf[tile_face_index(L, FZ, K + 1, 0, l, pa, pb)] = timg[row0 + TILE_Z - FZ + l];
+                }
+            }
             if (lane == 0) {
                 state[tile].y = P.epoch;
                 atomicOr(&P.changed[s], CHANGED_IMPROVED);
@@ -486,7 +553,11 @@ static tile_sweep_fn tile_instance(const TileSweep &P)
 
 static bool tile_sweep_ok(const TileSweep &P)
 {
-    return P.R >= 1 && P.R <= TILE_MAX_R && P.nent >= 1 && P.nent <= TILE_MAX_ENT;
+    static_assert(TILE_ZF == 4, "the z halo of an image row is one float4 on either side");
+    return P.R >= 1 && P.R <= TILE_MAX_R && P.nent >= 1 && P.nent <= TILE_MAX_ENT
+        && P.fz >= 1 && P.fz <= TILE_ZF && P.vface && P.tface
+        && P.L.lo[0] == P.R && P.L.lo[1] == P.R && P.L.lo[2] >= TILE_ZF && P.L.lo[2] % TILE_Z == 0   // whole-line rows
+        && P.L.s1 % TILE_Z == 0;
 }
 
 hipError_t tile_sweep_wgs_per_cu(const TileSweep &P, int *wgs)
