@@ -347,6 +347,7 @@ tile_sweep_kernel(TileSweep P, const int2 *__restrict__ list, const int *__restr
     // start descriptor then come through the scalar cache and the buffer descriptors need no
     // waterfall loop)
     const int nwg = uni((int)gridDim.x), ntodo = uni(count);
+    int flagged = -1;           // start whose "improved" bit this workgroup has set in this launch
     for (int next = uni((int)blockIdx.x); next < ntodo; next = uni(next + nwg)) {
         const const_item_ptr ip_ = (const_item_ptr)(list + next);
         const int s = ip_->s, tile = ip_->tile;
@@ -500,9 +501,12 @@ tile_sweep_kernel(TileSweep P, const int2 *__restrict__ list, const int *__restr
                     tf[tile_face_index(L, FZ, K + 1, 0, l, pa, pb)] = timg[row0 + TILE_Z - FZ + l];
                 }
             }
-            if (lane == 0) {
-                state[tile].y = P.epoch;
-                atomicOr(&P.changed[s], CHANGED_IMPROVED);
+            if (lane == 0) state[tile].y = P.epoch;
+            // (once per workgroup and start: the list is sorted by start, and an atomic per
+            // improved tile on the starts' few words holds every tile up - see the planner)
+            if (s != flagged) {
+                if (lane == 0) atomicOr(&P.changed[s], CHANGED_IMPROVED);
+                flagged = s;
             }
         }
         // (the image is overwritten by the next tile's loads: every read of it has been
