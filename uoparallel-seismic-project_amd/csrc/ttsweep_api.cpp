@@ -1040,8 +1040,9 @@ static int solve_device_body(ttsweep_ctx *ctx, int nstart, const ttsweep_start *
             HIPCHK(launch_init_tile_flags(L, sd, /*from_box=*/!init, ctx->stream));
         if (ctx->kernel == TTSWEEP_KERNEL_TILE) {
             HIPCHK(launch_init_tile_state(L, sd, /*from_box=*/!init, ctx->stream));
-            HIPCHK(launch_build_tile_faces(L, sd.T, ctx->d_tface + (size_t)s * tile_face_cells(L, ctx->tile_fz),
-                                           ctx->tile_fz, ctx->stream));
+            float *const faces = ctx->d_tface + (size_t)s * tile_face_cells(L, ctx->tile_fz);
+            if (init) HIPCHK(launch_init_tile_faces(L, faces, ctx->tile_fz, sd.sa, sd.sb, sd.sc, ctx->stream));
+            else HIPCHK(launch_build_tile_faces(L, sd.T, faces, ctx->tile_fz, ctx->stream));
         }
         ctx->h_active[s] = s;
     }
@@ -1097,9 +1098,14 @@ static int solve_device_body(ttsweep_ctx *ctx, int nstart, const ttsweep_start *
             int *hch_slot = ctx->h_changed + (size_t)slot * nstart;
             const bool strip = ctx->kernel == TTSWEEP_KERNEL_STRIP;
             if (!strip) HIPCHK(hipMemsetAsync(dch, 0, nstart * sizeof(int), ctx->stream));
+            const auto t_enq = std::chrono::steady_clock::now();
             if (launch_pass(ctx, nactive, nstart, dch, hch_slot,
                             ctx->d_changed + (size_t)((launched + 1) % PASS_SLOTS) * nstart))
                 return -1;
+            if (trace)
+                fprintf(stderr, "   (host: %.0f us to enqueue pass %d)\n",
+                        std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_enq).count(),
+                        launched + 1);
             if (!strip)
                 HIPCHK(hipMemcpyAsync(hch_slot, dch, nstart * sizeof(int), hipMemcpyDeviceToHost,
                                       ctx->stream));

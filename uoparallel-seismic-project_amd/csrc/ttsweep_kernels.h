@@ -81,6 +81,8 @@ hipError_t launch_init_tile_flags(const DevLayout &L, const StartDesc &sd, bool 
 size_t tile_lds_bytes(int R);
 // faces[...] = the z faces (ttsweep_dev.h: tile_face_index) of a padded volume
 hipError_t launch_build_tile_faces(const DevLayout &L, const float *padded, float *faces, int fz, hipStream_t st);
+// the faces of an initialised box (+INFINITY everywhere, 0 at the start cell (sa, sb, sc))
+hipError_t launch_init_tile_faces(const DevLayout &L, float *faces, int fz, int sa, int sb, int sc, hipStream_t st);
 hipError_t tile_sweep_wgs_per_cu(const TileSweep &P, int *wgs);
 hipError_t launch_tile_sweep(const TileSweep &P, int2 *list, int *ctrl, int nblocks, hipStream_t st);
 // from_box = false: only the start's tile counts as changed; true: every tile does.

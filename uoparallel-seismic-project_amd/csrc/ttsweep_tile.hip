@@ -81,6 +81,30 @@ build_tile_faces_kernel(DevLayout L, const float *__restrict__ padded, float *__
     faces[t] = padded[(long long)pa * L.s0 + (long long)pb * L.s1 + (c + L.lo[2])];
 }
 
+// The faces of a freshly initialised box (+INFINITY, 0 at the start cell) without reading it.
+__global__ void __launch_bounds__(256)
+init_tile_faces_kernel(DevLayout L, float *__restrict__ faces, int fz, long long n, int sa, int sb, int sc)
+{
+    const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (t >= n) return;
+    const int pb = (int)(t % L.p[1]);
+    long long u = t / L.p[1];
+    const int pa = (int)(u % L.p[0]);  u /= L.p[0];
+    const int layer = (int)(u % fz);   u /= fz;
+    const int side = (int)(u & 1), kb = (int)(u >> 1);
+    const int c = TILE_Z * kb + (side ? layer : layer - fz);
+    faces[t] = (pa == sa + L.lo[0] && pb == sb + L.lo[1] && c == sc) ? 0.0f : __builtin_inff();
+}
+
+hipError_t launch_init_tile_faces(const DevLayout &L, float *faces, int fz, int sa, int sb, int sc, hipStream_t st)
+{
+    if (fz < 1 || fz > TILE_ZF) return hipErrorInvalidValue;
+    const long long n = tile_face_cells(L, fz);
+    hipLaunchKernelGGL(init_tile_faces_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, L, faces, fz, n,
+                       sa, sb, sc);
+    return hipGetLastError();
+}
+
 hipError_t launch_build_tile_faces(const DevLayout &L, const float *padded, float *faces, int fz, hipStream_t st)
 {
     if (fz < 1 || fz > TILE_ZF || L.lo[2] < fz) return hipErrorInvalidValue;
