@@ -415,6 +415,35 @@ def test_tile_kernel_small_stars_vs_oracle(P, oracle, shape, seed):
             assert_bit_equal(b, a, f"{name} re-solved")
 
 
+@pytest.mark.parametrize("shape,seed", [((20, 37, 97), 41), ((40, 9, 70), 42)])
+def test_tile_kernel_resumes_from_a_damaged_box(P, oracle, shape, seed):
+    """TILE kernel started from a box that is not a fresh one (init = 0): a converged box with a
+    block reset to INFINITY and another raised is still a state above the fixed point, so the
+    solve has to return 1 and restore the converged box bit for bit (tile activity and the z
+    faces are then derived from the box, not from the start point)."""
+    rng = np.random.default_rng(seed)
+    v = rng.uniform(0.1, 0.5, size=shape).astype(np.float32)
+    six = P.inputs.read_triples(P.inputs.star_path("six"))
+    rnd = np.stack([rng.integers(-2, 3, size=9), rng.integers(-2, 3, size=9), rng.integers(-4, 5, size=9)], axis=1)
+    rnd = rnd[np.any(rnd != 0, axis=1)].astype(np.int32)
+    for name, offs in (("six", six), ("random", rnd)):
+        starts = np.stack([rng.integers(0, n, size=2) for n in shape], axis=1).astype(np.int32)
+        fs = P.inputs.make_fs(offs)
+        tts, rc, st = gpu_converge(P, v, fs, starts, kernel=3)
+        assert st["kernel_variant"] == 3
+        damaged = [t.copy() for t in tts]
+        for t, start in zip(damaged, starts):
+            lo = [int(rng.integers(0, n)) for n in shape]
+            hi = [min(n, l + int(rng.integers(1, 40))) for n, l in zip(shape, lo)]
+            t[lo[0]:hi[0], lo[1]:hi[1], lo[2]:hi[2]] = np.inf
+            t[: shape[0] // 2, :, 30:36] *= np.float32(1.5)
+            t[tuple(start)] = 0
+        fixed, rc2, st2 = gpu_converge(P, v, fs, starts, tts=damaged, kernel=3)
+        assert rc2 == 1 and st2["kernel_variant"] == 3
+        for a, b, start in zip(fixed, tts, starts):
+            assert_bit_equal(a, b, f"{name} {shape} start {start} after damage")
+
+
 def test_tile_kernel_512_grid_matches_cell_kernel(P):
     """The HBM-bound regime at size: 6-neighbour star on 512x512x256, two starts.  TILE
     (ordered sweeps) and CELL (one hop per pass, an independent implementation) agree bit for
