@@ -494,7 +494,7 @@ static size_t flag_words(const DevLayout &L)
 {
     const size_t strip = 3 * (size_t)std::max(strip_units(L, 1), 1) + 4;      // (one-plane units: the larger grid)
     const size_t tile = 2 * (size_t)tile_count(L.n[0], TILE_X) * tile_count(L.n[1], TILE_Y) * tile_count(L.n[2], TILE_Z);
-    return std::max(strip, tile);
+    return (std::max(strip, tile) + 1) & ~(size_t)1;       // (even: the TILE kernel views them as int2)
 }
 
 static int ensure_capacity(ttsweep_ctx *ctx, int nstart)
@@ -699,6 +699,9 @@ static int launch_pass(ttsweep_ctx *ctx, int nactive, int nstart, int *d_changed
         P.sy = (o & 2) ? -1 : 1;
         P.sz = (o & 4) ? -1 : 1;
         P.nent = ctx->tile_nent;
+        P.state0 = ctx->d_tile_flags;
+        P.state_stride = (long long)flag_words(ctx->L);
+        P.work0 = ctx->d_work;
         P.fz = ctx->tile_fz;
         P.vface = ctx->d_vface;
         P.tface = ctx->d_tface;

@@ -154,7 +154,7 @@ tile_plan_kernel(TileSweep P, int2 *__restrict__ list, int *__restrict__ ctrl)
             const int J = P.sy > 0 ? Jp : P.NJ - 1 - Jp;
             const int K = P.sz > 0 ? Kp : P.NK - 1 - Kp;
             s = P.active[u];
-            int2 *__restrict__ state = reinterpret_cast<int2 *>(P.starts[s].tile_flags);
+            int2 *__restrict__ state = reinterpret_cast<int2 *>(P.state0 + (long long)s * P.state_stride);
             tile = (I * P.NJ + J) * P.NK + K;
             const int relaxed = state[tile].x;
             int newest = INT_MIN;
@@ -187,7 +187,7 @@ tile_plan_kernel(TileSweep P, int2 *__restrict__ list, int *__restrict__ ctrl)
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
         if (lane == first) {
-            unsigned long long *const work = P.starts[s0].work;
+            unsigned long long *const work = P.work0 + 3 * s0;
             atomicAdd(work, (unsigned long long)sum * (unsigned long long)P.nent);
             atomicAdd(work + 2, (unsigned long long)__popcll(mm));
         }
@@ -583,7 +583,7 @@ static bool tile_sweep_ok(const TileSweep &P)
 {
     static_assert(TILE_ZF == 4, "the z halo of an image row is one float4 on either side");
     return P.R >= 1 && P.R <= TILE_MAX_R && P.nent >= 1 && P.nent <= TILE_MAX_ENT
-        && P.fz >= 1 && P.fz <= TILE_ZF && P.vface && P.tface
+        && P.fz >= 1 && P.fz <= TILE_ZF && P.vface && P.tface && P.state0 && P.work0
         && P.L.lo[0] == P.R && P.L.lo[1] == P.R && P.L.lo[2] >= TILE_ZF && P.L.lo[2] % TILE_Z == 0   // whole-line rows
         && P.L.s1 % TILE_Z == 0;
 }
