@@ -1246,6 +1246,19 @@ int ttsweep_solve(ttsweep_ctx *ctx, int nstart, const ttsweep_start *starts,
         std::vector<float *> ptrs(n);
         std::vector<char> pinned(n, 0);
         int rc = 0;
+#ifdef TTSWEEP_DEBUG_ENV
+        const bool trace = getenv("TTSWEEP_TRACE") != nullptr;
+#else
+        const bool trace = false;
+#endif
+        auto t_phase = std::chrono::steady_clock::now();
+        auto lap = [&](const char *what) {
+            if (!trace) return;
+            (void)hipStreamSynchronize(ctx->stream);
+            const auto now = std::chrono::steady_clock::now();
+            fprintf(stderr, "ttsweep_solve: %s %.1f ms\n", what, std::chrono::duration<double, std::milli>(now - t_phase).count());
+            t_phase = now;
+        };
         for (int s = 0; s < n; s++) {
             ptrs[s] = stage + (size_t)s * cells;
             if (hipHostRegister(tt_host[first + s], cells * sizeof(float), hipHostRegisterDefault) == hipSuccess)
@@ -1253,13 +1266,16 @@ int ttsweep_solve(ttsweep_ctx *ctx, int nstart, const ttsweep_start *starts,
             else
                 (void)hipGetLastError();
         }
+        lap("pin the caller's boxes");
         for (int s = 0; s < n && rc == 0; s++) {
             hipError_t e = hipMemcpyAsync(ptrs[s], tt_host[first + s], cells * sizeof(float),
                                           hipMemcpyHostToDevice, ctx->stream);
             if (e != hipSuccess) rc = set_error("travel-time upload failed: %s", hipGetErrorString(e));
         }
+        lap("upload");
         if (rc == 0) rc = ttsweep_solve_device(ctx, n, starts + first, ptrs.data(), 0);
-        if (rc >= 0) {
+        lap("solve");
+        if (rc > 0) {       // (rc == 0: nothing was stored, the caller's boxes are the result already)
             for (int s = 0; s < n; s++) {
                 hipError_t e = hipMemcpyAsync(tt_host[first + s], ptrs[s], cells * sizeof(float),
                                               hipMemcpyDeviceToHost, ctx->stream);
@@ -1273,9 +1289,11 @@ int ttsweep_solve(ttsweep_ctx *ctx, int nstart, const ttsweep_start *starts,
             hipError_t e = hipStreamSynchronize(ctx->stream);
             if (e != hipSuccess && rc >= 0) rc = set_error("travel-time transfer failed: %s", hipGetErrorString(e));
         }
+        lap("download");
         for (int s = 0; s < n; s++)
             if (pinned[s]) (void)hipHostUnregister(tt_host[first + s]);
         (void)hipFree(stage);
+        lap("unpin, free");
         if (rc < 0) return rc;
         any |= rc;
         // accumulate the per-batch counters into one report
