@@ -779,15 +779,29 @@ __device__ __forceinline__ void relax_special_cell(const DevLayout &L, const flo
     const float vc = v[ci];
     const float told = T[ci];
     float best = told;
-    for (int e = lane; e < nentries; e += 64) {
-        const CellEntry en = entries[e];
-        const long long oi = ci + en.delta;
-        const bool live = ((en.flags & PULL_FWD) && !c_is_start)
-                       || ((en.flags & PULL_REV) && oi != sd.sidx);
-        const float sum = vc + v[oi];
-        const float delay = en.h * sum;
-        const float cand = delay + T[oi];
-        if (live && cand < best) best = cand;
+    // (eight entries per lane at a time, all their loads in flight together: this runs at the
+    // head of every pass)
+    constexpr int U = 8;
+    for (int e0 = 0; e0 < nentries; e0 += 64 * U) {
+        CellEntry en[U];
+        float vo[U], to[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) en[u] = entries[min(e0 + u * 64 + lane, nentries - 1)];
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            vo[u] = v[ci + en[u].delta];
+            to[u] = T[ci + en[u].delta];
+        }
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const long long oi = ci + en[u].delta;
+            const bool live = e0 + u * 64 + lane < nentries
+                           && (((en[u].flags & PULL_FWD) && !c_is_start) || ((en[u].flags & PULL_REV) && oi != sd.sidx));
+            const float sum = vc + vo[u];
+            const float delay = en[u].h * sum;
+            const float cand = delay + to[u];
+            if (live && cand < best) best = cand;
+        }
     }
 #pragma unroll
     for (int w = 32; w >= 1; w >>= 1) best = fminf(best, __shfl_xor(best, w));
@@ -921,6 +935,10 @@ sweep_units_kernel(DevLayout L, const float *__restrict__ v, const StartDesc *__
     }
     int *plane_nent = item_range + NS * 16;         // offsets per staged plane and own plane (statistics)
     if (tid < 32) plane_nent[tid] = (tid >> 1) < plan.nstaged ? plan.nent[tid >> 1][tid & 1] : 0;
+    // the queue lengths are final when this kernel starts (the planner wrote them): read them
+    // once - an empty queue then costs no memory round trip, and an empty pass none at all
+    int *qcount = head + 2;                         // [0 .. nlists)
+    if (tid < UNITQ_LISTS) qcount[tid] = tid < nlists ? ctrl[tid] : 0;
     __syncthreads();
 
     // ---- the dead-edge cells of the active starts, one wave per cell
@@ -944,10 +962,11 @@ sweep_units_kernel(DevLayout L, const float *__restrict__ v, const StartDesc *__
         // all queues exhausted)
         PROF_T(t_top);
         const int q = (home + probe) % nlists;
-        const int n = ctrl[q];
+        const int n = __builtin_amdgcn_readfirstlane(qcount[q]);
+        if (n == 0) { probe++; continue; }          // (uniform: nothing was asked of an empty queue)
         if (tid == 0) {
             int j = ahead;
-            if (j < 0) j = ctrl[UNITQ_LISTS + q] < n ? atomicAdd(&ctrl[UNITQ_LISTS + q], 1) : n;
+            if (j < 0) j = atomicAdd(&ctrl[UNITQ_LISTS + q], 1);
             head[it & 1] = j;
         }
         __syncthreads();
@@ -1157,20 +1176,24 @@ sweep_units_kernel(DevLayout L, const float *__restrict__ v, const StartDesc *__
 
     // ---- the last workgroup to leave closes the pass: it hands the "changed" words to the
     // host (pinned memory) and clears the queue counters and the next pass's words, so a pass
-    // needs no memset / copy commands around its two kernels
+    // needs no memset / copy commands around its two kernels.  All its threads take part (one
+    // start each: the words are read with an atomic, a round trip apiece - done one after the
+    // other by a single thread they cost 24 round trips per pass on the headline workload).
     __syncthreads();
     if (tid == 0) {
         __threadfence();
-        int *done = ctrl + UNITQ_CTRL_WORDS;
-        if (atomicAdd(done, 1) == (int)gridDim.x - 1) {
-            for (int s = 0; s < tail.nstart; s++) {
-                tail.changed_host[s] = atomicOr(&changed[s], 0);
-                tail.changed_next[s] = 0;
-            }
-            for (int k = 0; k < UNITQ_CTRL_WORDS; k++) ctrl[k] = 0;
-            *done = 0;
-            __threadfence_system();
+        head[0] = atomicAdd(ctrl + UNITQ_CTRL_WORDS, 1) == (int)gridDim.x - 1;
+    }
+    __syncthreads();
+    if (head[0]) {
+        for (int s = tid; s < tail.nstart; s += STRIP_TB * NS) {
+            tail.changed_host[s] = atomicOr(&changed[s], 0);
+            tail.changed_next[s] = 0;
         }
+        if (tid < UNITQ_CTRL_WORDS) ctrl[tid] = 0;
+        __threadfence_system();
+        __syncthreads();
+        if (tid == 0) ctrl[UNITQ_CTRL_WORDS] = 0;
     }
 }
 
