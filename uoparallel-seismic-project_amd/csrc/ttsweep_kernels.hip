@@ -677,11 +677,13 @@ hipError_t launch_init_tile_flags(const DevLayout &L, const StartDesc &sd, bool 
 // at a time, its four waves splitting the items of every staged plane among themselves
 // (nearly equal shares, StripPlan::wsplit) and min-combining their partial results through LDS.
 
+struct PlaneCounts { int n[STRIP_STAGED][STRIP_PLANES]; };     // StripPlan::nent (offsets per staged plane and own plane)
+
 __global__ void __launch_bounds__(256)
 plan_pass_kernel(DevLayout L, const StartDesc *__restrict__ starts, const int2 *__restrict__ work,
                  long long nwork, int *__restrict__ changed, int4 *__restrict__ lists, int list_cap,
                  int *__restrict__ ctrl, int nlists, int ra, int np, int btiles, int cstrips, int parity,
-                 float gate_r2)
+                 float gate_r2, PlaneCounts pc)
 {
     // wave W handles 64 consecutive entries of ONE XCD's sub-list, so that a wave-level
     // compaction keeps the work-list order (nearest to the start first) inside a queue
@@ -746,9 +748,37 @@ plan_pass_kernel(DevLayout L, const StartDesc *__restrict__ starts, const int2 *
     int base = 0;
     if (lane == 0) base = atomicAdd(&ctrl[x], __popcll(due_lanes));
     base = __shfl(base, 0);
+    unsigned long long relax = 0;               // cells x offsets this unit will relax (statistics)
     if (planes != 0) {
         const int rank = __popcll(due_lanes & ((1ull << lane) - 1ull));
         lists[(size_t)x * list_cap + base + rank] = make_int4(s, unit, (int)planes, 0);
+        int u = unit;
+        const int cs = u % cstrips;  u /= cstrips;
+        const int bt = u % btiles;   u /= btiles;
+        const int wb = min(min(STRIP_TB, L.n[1]), L.n[1] - bt * STRIP_TB), wc = max(min(STRIP_K, L.n[2] - cs * STRIP_K), 0);
+        const bool two = np > 1 && np * u + 1 < L.n[0];
+        int nent = 0;
+        for (int p = 0; p < 2 * ra + np; p++)
+            if ((planes >> p) & 1u) nent += pc.n[p][0] + (two ? pc.n[p][1] : 0);
+        relax = (unsigned long long)(wb * wc) * (unsigned long long)nent;
+    }
+    // The starts' work counters: one pair of atomics per wavefront and start here, not per unit
+    // in the sweep kernel (where the few words of a small shard's starts were a hot spot that
+    // every unit's first wave waited on: 3 starts 17.2 -> 16.6 ms).
+    unsigned long long rest = due_lanes;
+    while (rest) {
+        const int first = __builtin_ctzll(rest);
+        const int s0 = __shfl(s, first);
+        const bool mine = planes != 0 && s == s0;
+        const unsigned long long mm = __ballot(mine);
+        unsigned long long sum = mine ? relax : 0ull;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+        if (lane == first) {
+            atomicAdd(starts[s0].work, sum);
+            atomicAdd(starts[s0].work + 2, (unsigned long long)__popcll(mm));
+        }
+        rest &= ~mm;
     }
 }
 
@@ -933,8 +963,6 @@ sweep_units_kernel(DevLayout L, const float *__restrict__ v, const StartDesc *__
             packed = (plan.first[p] + plan.wsplit[p][w]) | ((plan.first[p] + plan.wsplit[p][w + 1]) << 16);
         item_range[tid] = packed;
     }
-    int *plane_nent = item_range + NS * 16;         // offsets per staged plane and own plane (statistics)
-    if (tid < 32) plane_nent[tid] = (tid >> 1) < plan.nstaged ? plan.nent[tid >> 1][tid & 1] : 0;
     // the queue lengths are final when this kernel starts (the planner wrote them): read them
     // once - an empty queue then costs no memory round trip, and an empty pass none at all
     int *qcount = head + 2;                         // [0 .. nlists)
@@ -957,6 +985,7 @@ sweep_units_kernel(DevLayout L, const float *__restrict__ v, const StartDesc *__
     // The index of the unit after the current one is asked for while the current one is being
     // relaxed (`ahead`, held by thread 0); -1: nothing asked for yet.
     int ahead = -1;
+    int flagged = -1;           // (lane 0 of a wave) the start whose "improved" bit this wave has set
     while (probe < nlists) {
         // ---- take the next unit of queue q (every wave leaves through the same exit:
         // all queues exhausted)
@@ -993,20 +1022,8 @@ sweep_units_kernel(DevLayout L, const float *__restrict__ v, const StartDesc *__
         const const_start_ptr sdp = (const_start_ptr)(starts + s);
         float *const T = sdp->T;
         int *const tile_flags = sdp->tile_flags;
-        unsigned long long *const work = sdp->work;
         const int box_lo0 = sdp->box_lo[0], box_lo1 = sdp->box_lo[1], box_lo2 = sdp->box_lo[2];
         const int box_hi0 = sdp->box_hi[0], box_hi1 = sdp->box_hi[1], box_hi2 = sdp->box_hi[2];
-        const int nplanes = min(NP, L.n[0] - a0);   // own planes inside the grid
-        if (tid == 0) {     // statistics: cells x offsets relaxed, units
-            const int wb = min(tb_eff, L.n[1] - b0), wc = max(min(K, L.n[2] - c0), 0);
-            int nent = 0;
-#pragma unroll
-            for (int p = 0; p < 16; p++)
-                if ((my_planes >> p) & 1u) nent += plane_nent[2 * p] + (nplanes > 1 ? plane_nent[2 * p + 1] : 0);
-            atomicAdd(work, (unsigned long long)(wb * wc) * (unsigned long long)nent);
-            atomicAdd(work + 2, 1ull);
-        }
-
         // ---- staged planes to relax against, in order; the first one starts to load right
         // away.  Slab of staged plane p (plane a0 - ra + p): rows b0-rb .. b0+63+rb, columns
         // c0-CF .. c0+K+CF-1.
@@ -1155,7 +1172,9 @@ sweep_units_kernel(DevLayout L, const float *__restrict__ v, const StartDesc *__
         for (int w = 32; w >= 1; w >>= 1) improved |= __shfl_xor(improved, w);
         if (lane == 0 && improved) {
             atomicOr(tile_flags + parity * nflag + (a * btiles + bt) * cstrips + cs, improved);
-            atomicOr(&changed[s], CHANGED_IMPROVED);
+            // (the start's word: once per wave, start and pass - its few words are a hot spot)
+            if (s != flagged) atomicOr(&changed[s], CHANGED_IMPROVED);
+            flagged = s;
         }
 #ifdef TTSWEEP_PROFILE
         if (tid == 0) {
@@ -1217,9 +1236,12 @@ hipError_t launch_plan_pass(const DevLayout &L, const StartDesc *starts, const i
     const long long waves = ((per_list + 63) / 64) * nlists;
     const long long nblocks = (waves + 3) / 4;
     if (nblocks > 0x7fffffffLL) return hipErrorInvalidValue;
+    PlaneCounts pc;
+    for (int p = 0; p < STRIP_STAGED; p++)
+        for (int j = 0; j < STRIP_PLANES; j++) pc.n[p][j] = p < plan.nstaged ? plan.nent[p][j] : 0;
     hipLaunchKernelGGL(plan_pass_kernel, dim3((unsigned)nblocks), dim3(256), 0, st, L, starts, work,
                        nwork, changed, lists, list_cap, ctrl, nlists, plan.ra, plan.np, btiles, strip_cstrips(L),
-                       parity, gate_r2);
+                       parity, gate_r2, pc);
     return hipGetLastError();
 }
 
