@@ -986,6 +986,9 @@ sweep_units_kernel(DevLayout L, const float *__restrict__ v, const StartDesc *__
     // relaxed (`ahead`, held by thread 0); -1: nothing asked for yet.
     int ahead = -1;
     int flagged = -1;           // (lane 0 of a wave) the start whose "improved" bit this wave has set
+#ifdef TTSWEEP_PROFILE
+    unsigned long long prof_acc[7] = {};
+#endif
     while (probe < nlists) {
         // ---- take the next unit of queue q (every wave leaves through the same exit:
         // all queues exhausted)
@@ -1177,20 +1180,24 @@ sweep_units_kernel(DevLayout L, const float *__restrict__ v, const StartDesc *__
             flagged = s;
         }
 #ifdef TTSWEEP_PROFILE
-        if (tid == 0) {
+        {   // (summed per workgroup, added to the totals once at its end: seven atomics per unit
+            // on eight words would be part of what is being measured)
             const long long t_end = clock64();
-            atomicAdd(&g_prof[0], (unsigned long long)(t_fetch - t_top));
-            atomicAdd(&g_prof[1], (unsigned long long)(t_pro - t_fetch));
-            atomicAdd(&g_prof[2], (unsigned long long)p_wait);
-            atomicAdd(&g_prof[3], (unsigned long long)p_stage);
-            atomicAdd(&g_prof[4], (unsigned long long)p_comp);
-            atomicAdd(&g_prof[5], (unsigned long long)(t_end - t_loop));
-            atomicAdd(&g_prof[6], 1ull);
+            prof_acc[0] += (unsigned long long)(t_fetch - t_top);
+            prof_acc[1] += (unsigned long long)(t_pro - t_fetch);
+            prof_acc[2] += (unsigned long long)p_wait;
+            prof_acc[3] += (unsigned long long)p_stage;
+            prof_acc[4] += (unsigned long long)p_comp;
+            prof_acc[5] += (unsigned long long)(t_end - t_loop);
+            prof_acc[6] += 1ull;
         }
 #endif
     }
 #ifdef TTSWEEP_PROFILE
-    if (tid == 0) atomicAdd(&g_prof[7], (unsigned long long)(clock64() - t_k0));
+    if (tid == 0) {
+        for (int i = 0; i < 7; i++) if (prof_acc[6]) atomicAdd(&g_prof[i], prof_acc[i]);
+        atomicAdd(&g_prof[7], (unsigned long long)(clock64() - t_k0));
+    }
 #endif
 
     // ---- the last workgroup to leave closes the pass: it hands the "changed" words to the
