@@ -256,12 +256,6 @@ static void make_layout_tile(ttsweep_ctx *ctx)
         L.lo[d] = d < 2 ? ctx->tile_R : TILE_Z;         // (a whole tile in front: tile rows are whole lines)
         L.p[d] = tile_count(n[d], t[d]) * t[d] + 2 * L.lo[d];
     }
-#ifdef TTSWEEP_TILE_ZPAD        // experiment: row / plane pitch against memory-channel aliasing
-    L.p[2] += TTSWEEP_TILE_ZPAD;
-#endif
-#ifdef TTSWEEP_TILE_YPAD
-    L.p[1] += TTSWEEP_TILE_YPAD;
-#endif
     L.s1 = L.p[2];
     L.s0 = (long long)L.p[1] * L.p[2];
     L.cells = L.s0 * L.p[0];
