@@ -82,8 +82,11 @@ typedef struct ttsweep_ctx ttsweep_ctx;
                                           pass; 0 switches the gate off (default: half the
                                           star's reach) */
 #define TTSWEEP_OPT_PAIR_MIN_STARTS 7 /* schedule only: the STRIP kernel relaxes units of two planes
-                                         (throughput) from this many starts per solve on, units of
-                                         one plane (latency) below */
+                                         from this many starts per solve on, units of one plane
+                                         below (0: always two, a huge value: never).  Default
+                                         without this option: two planes when the solve offers
+                                         enough units to keep the device busy with them (starts x
+                                         one-plane units of a start >= 80 000), else one */
 #define TTSWEEP_OPT_GATE_R0_MILLI 6   /* schedule only: gate radius of the first pass, cells x 1/1000
                                          (default: the star's reach + 1) */
 

@@ -81,7 +81,8 @@ struct ttsweep_ctx {
     StripItem *d_strip_items[STRIP_PLANES] = {nullptr, nullptr};
     StripPlan plans[STRIP_PLANES]{};
     int np = STRIP_PLANES;
-    int pair_min_starts = 8;                // two-plane units from this many starts on (measured crossover)
+    int pair_min_starts = -1;               // two-plane units from this many starts on; -1: by the supply of units
+    long long pair_min_units = 80000;       //   (starts x one-plane units of a start; measured crossover)
     std::vector<std::array<int, 3>> special_offsets;   // device-axis offsets e: cell start - e owns a dead edge
     bool start_is_special = false;
     int max_box_cells = 0;                  // of the current solve
@@ -916,7 +917,7 @@ int ttsweep_set_option(ttsweep_ctx *ctx, int key, long long value)
         return 0;
     case TTSWEEP_OPT_PAIR_MIN_STARTS:
         if (value < 0) return set_error("start count must be >= 0");
-        ctx->pair_min_starts = (int)std::min<long long>(value, 1 << 30);
+        ctx->pair_min_starts = (int)std::min<long long>(value, 1 << 30);      // (>= 0: the explicit rule from now on)
         return 0;
     case TTSWEEP_OPT_GATE_R0_MILLI:
         if (value < 0) return set_error("gate start radius must be >= 0");
@@ -1010,7 +1011,10 @@ static int solve_device_body(ttsweep_ctx *ctx, int nstart, const ttsweep_start *
     const DevLayout &L = ctx->L;
     HIPCHK(hipEventRecord(ctx->ev_solve0, ctx->stream));
     // units of two planes when there are starts enough to fill the machine with them
-    const int np = nstart >= ctx->pair_min_starts ? STRIP_PLANES : 1;
+    const bool pairs = ctx->pair_min_starts >= 0
+        ? nstart >= ctx->pair_min_starts
+        : (long long)nstart * strip_units(L, 1) >= ctx->pair_min_units;
+    const int np = pairs ? STRIP_PLANES : 1;
     if (np != ctx->np) ctx->unit_order_key.assign(ctx->unit_order_key.size(), -1);     // orders belong to the other unit grid
     ctx->np = np;
 
