@@ -133,6 +133,41 @@ def test_resume_and_idempotence(P, golden24, oracle):
     assert_bit_equal(tt, before, "idempotent")
 
 
+@pytest.mark.parametrize("kernel", [1, 2, 3])
+def test_convergence_cap_error_leaves_the_context_usable(P, oracle, kernel):
+    """An error inside the driver loop (here: the sweep cap, TTSWEEP_OPT_MAX_SWEEPS) is reported,
+    the passes already queued are drained, and the same context then solves the same problem
+    correctly (the round-1 review's robustness item)."""
+    rng = np.random.default_rng(90 + kernel)
+    shape = (37, 34, 45)
+    v = rng.uniform(0.1, 0.5, size=shape).astype(np.float32)
+    offs = P.inputs.read_triples(P.inputs.star_path("six" if kernel == 3 else "3"))
+    fs = P.inputs.make_fs(offs)
+    starts = np.array([[3, 30, 7], [35, 2, 40]], np.int32)
+
+    def fresh():
+        out = []
+        for st in starts:
+            t = np.full(shape, np.inf, np.float32)
+            t[tuple(st)] = 0
+            out.append(t)
+        return out
+
+    with P.TravelTimeSolver(shape, fs) as sol:
+        sol.set_option(P.OPT_KERNEL, kernel)
+        sol.set_velocity(v)
+        sol.set_option(P.OPT_MAX_SWEEPS, 2)
+        with pytest.raises(Exception, match="did not converge"):
+            sol.solve(starts, fresh())
+        sol.set_option(P.OPT_MAX_SWEEPS, 100000)
+        tts = fresh()
+        assert sol.solve(starts, tts) == 1
+        assert sol.stats()["kernel_variant"] == kernel
+    for st, tt in zip(starts, tts):
+        want, _, _ = oracle.converge(v, oracle.make_star(offs), st, order=1)
+        assert_bit_equal(tt, want, f"kernel {kernel} after the error, start {st}")
+
+
 def test_sweepXYZ_dropin(P, golden24):
     """ttsweep_sweepXYZ: non-zero on the first call, 0 on the next (drop-in contract)."""
     key = "3_mid"
