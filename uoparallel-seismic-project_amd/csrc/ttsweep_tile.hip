@@ -14,12 +14,15 @@
 //     I' + J' + K' (tile coordinates counted in sweep direction) are independent of each
 //     other for a 6-neighbour star and are relaxed by ONE launch pair: tile_plan_kernel lists
 //     the tiles of the hyperplane that are due (something near them changed since they were
-//     last relaxed), tile_sweep_kernel - a persistent grid of single-wavefront workgroups -
-//     drains the list; the launches of a sweep follow each other on the stream;
+//     last relaxed), tile_sweep_kernel - a persistent grid of single-wavefront workgroups,
+//     as many as the device holds at once - relaxes list entries b, b + grid, ... (no cursor,
+//     no per-tile atomics: see the planner); the launches of a sweep follow each other on
+//     the stream;
 //   * inside a tile, lane (i', j') walks its z-column: in step d it relaxes the cell with
-//     k' = d - i' - j', so every cell sees the values its three upwind neighbours got in
-//     step d - 1 (a systolic hyperplane sweep, 46 steps per tile, no barrier: the tile
-//     lives in the LDS of one wavefront).
+//     k' = d - i' - j' (the 6-neighbour instance: the two cells 2m, 2m + 1 with
+//     m = d - i' - j', software-pipelined - six_sweep), so every cell sees the values its
+//     three upwind neighbours got before it (a systolic hyperplane sweep, no barrier: the
+//     tile lives in the LDS of one wavefront).
 // For stars with diagonal offsets some neighbours lie on the same hyperplane; they are read
 // as they are (old or new).  As everywhere in this library that only affects the number of
 // sweeps: every value is the length of a real path and only ever decreases, so the result
