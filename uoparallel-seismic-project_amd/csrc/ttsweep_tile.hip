@@ -20,7 +20,7 @@
 //     the stream;
 //   * inside a tile, lane (i', j') walks its z-column: in step d it relaxes the cell with
 //     k' = d - i' - j' (the 6-neighbour instance: the two cells 2m, 2m + 1 with
-//     m = d - i' - j', software-pipelined - six_sweep), so every cell sees the values its
+//     m = d - i' - j', software-pipelined - sixc_sweep), so every cell sees the values its
 //     three upwind neighbours got before it (a systolic hyperplane sweep, no barrier: the
 //     tile lives in the LDS of one wavefront).
 // For stars with diagonal offsets some neighbours lie on the same hyperplane; they are read
@@ -237,99 +237,13 @@ typedef const __attribute__((address_space(4))) TileItem *const_item_ptr;
 // The 6-neighbour star with halo 1, entries in the pull star's order (sorted by offset):
 // image index deltas and everything derived from them are compile-time constants.
 constexpr int SIX_SY = TILE_Y + 2;
-constexpr int SIX_DEL[6] = {-SIX_SY * TILE_PITCH, -TILE_PITCH, -1, 1, TILE_PITCH, SIX_SY *TILE_PITCH};
 
-// The systolic sweep of the plain 6-neighbour star over the staged tile.  Lane (i', j') owns
-// the z-column (i', j') and relaxes TWO cells per step, k' = 2m and 2m + 1 with
-// m = d - i' - j' (30 steps for 8 x 8 x 32): the first cell's z-upwind neighbour is the lane's
-// own previous result, the second's is the first.  Software-pipelined: of a pair's inputs only
-// the travel times of its four lateral neighbour pairs can have been written in the previous
-// step (by other lanes; two of them really were, which two depends on the ordering); the
-// z-downwind values and all velocities cannot change before this lane is past them.  So a
-// step reads just those four pairs behind the previous step's writes, then - while they are on
-// their way - what the NEXT pair needs that is final already; the delays of the current pair
-// come from values that arrived a step ago.  The dependent chain of a step is one LDS round
-// trip plus about ten vector instructions, for two cells.  A step is also short in
-// instructions: one address register (every input is a compile-time offset from it: ZPOS is
-// the direction along z), 64-bit LDS accesses (a pair is 8-byte aligned), and the lateral
-// relaxations as packed operations over the pair.  Lanes outside their 16 steps run the same
-// instructions on in-image addresses and store nothing.  Entries in the pull star's order:
-// x-, y-, z-, z+, y+, x+.
 typedef float tile_f2 __attribute__((ext_vector_type(2)));
 
-template <bool ZPOS>
-__device__ __forceinline__ bool six_sweep(float *vimg, int t_off, int row0, int ij, int klo, unsigned span,
-                                          const TileSweep &P)
-{
-    static_assert(TILE_Z % 2 == 0 && TILE_ZF % 2 == 0 && TILE_PITCH % 2 == 0, "pairs must be 8-byte aligned");
-    constexpr int DP = ZPOS ? 2 : -2, DX = SIX_SY * TILE_PITCH, DY = TILE_PITCH;
-    constexpr int C = DX + 4;               // index of the current pair from the base below (every index >= 0)
-    // (opaque copies in vector registers: otherwise the lengths are re-read from the kernel
-    // arguments in every step)
-    float hxm = P.ent[0].h, hxp = P.ent[5].h, hym = P.ent[1].h, hyp = P.ent[4].h,
-          hzu = P.ent[ZPOS ? 2 : 3].h, hzd = P.ent[ZPOS ? 3 : 2].h;
-    asm volatile("" : "+v"(hxm), "+v"(hxp), "+v"(hym), "+v"(hyp), "+v"(hzu), "+v"(hzd));
-    const tile_f2 hxm2 = {hxm, hxm}, hxp2 = {hxp, hxp}, hym2 = {hym, hym}, hyp2 = {hyp, hyp};
-    // pairs in memory order (lower z first); FIRST / SECOND: the cell relaxed first / second
-#define FIRST(p) (ZPOS ? (p).x : (p).y)
-#define SECOND(p) (ZPOS ? (p).y : (p).x)
-#define LD2(i) (*reinterpret_cast<const tile_f2 *>(vb + (i)))
-    int m = -ij;                            // pair of this step: k' = 2m, 2m + 1
-    const float *vb = vimg + (row0 + (ZPOS ? 2 * m : TILE_Z - 2 - 2 * m) - C);      // the one address: advances by DP per step
-    tile_f2 vp = LD2(C), tp = LD2(t_off + C);                 // own pair
-    tile_f2 nv = LD2(C + DP), nt = LD2(t_off + C + DP);       // own next pair
-    float vzu = SECOND(LD2(C - DP)), tzu = SECOND(LD2(t_off + C - DP));     // own previous cell
-    tile_f2 vxm = LD2(C - DX), vxp = LD2(C + DX), vym = LD2(C - DY), vyp = LD2(C + DY);
-    bool improved = false;
-#pragma unroll 2
-    for (int d = 0; d < TILE_X + TILE_Y + TILE_Z / 2 - 2; d++, m++, vb += DP) {
-        // possibly written in the previous step: asked for first
-        tile_f2 txm = LD2(t_off + C - DX), txp = LD2(t_off + C + DX), tym = LD2(t_off + C - DY), typ = LD2(t_off + C + DY);
-        __builtin_amdgcn_sched_barrier(0);
-        // final already, wanted by the next pair (and the pair after it along the column)
-        const tile_f2 n_vxm = LD2(C + DP - DX), n_vxp = LD2(C + DP + DX), n_vym = LD2(C + DP - DY), n_vyp = LD2(C + DP + DY);
-        const tile_f2 n_nv = LD2(C + 2 * DP), n_nt = LD2(t_off + C + 2 * DP);
-        __builtin_amdgcn_sched_barrier(0);
-        // this pair: lateral delays (both cells at once), the column's delays and candidates
-        const tile_f2 lxm = hxm2 * (vp + vxm), lxp = hxp2 * (vp + vxp), lym = hym2 * (vp + vym), lyp = hyp2 * (vp + vyp);
-        const float vf = FIRST(vp), vs = SECOND(vp), tf = FIRST(tp), ts = SECOND(tp);
-        const float sfs = vf + vs;
-        const float czu_f = hzu * (vf + vzu) + tzu;             // first cell from its z-upwind neighbour
-        const float czd_f = hzd * sfs + ts;                     // first from second (old value)
-        const float lzu_s = hzu * sfs;                          // second from first (this step's result)
-        const float czd_s = hzd * (vs + FIRST(nv)) + FIRST(nt); // second from the next pair's first
-        float pre_f = fminf(tf, fminf(czu_f, czd_f)), pre_s = fminf(ts, czd_s);
-        const bool mine_f = (unsigned)(2 * m - klo) < span, mine_s = (unsigned)(2 * m + 1 - klo) < span;
-        asm volatile("" : "+v"(pre_f), "+v"(pre_s), "+v"(txm), "+v"(txp), "+v"(tym), "+v"(typ));  // (all lanes, before the four arrive)
-        const tile_f2 cxm = lxm + txm, cxp = lxp + txp, cym = lym + tym, cyp = lyp + typ;
-        pre_s = fminf(fminf(pre_s, fminf(SECOND(cxm), SECOND(cxp))), fminf(SECOND(cym), SECOND(cyp)));
-        float best_f = fminf(fminf(pre_f, fminf(FIRST(cxm), FIRST(cxp))), fminf(FIRST(cym), FIRST(cyp)));
-        best_f = mine_f ? best_f : tf;
-        float best_s = fminf(pre_s, lzu_s + best_f);
-        best_s = mine_s ? best_s : ts;
-        asm volatile("" : "+v"(best_f), "+v"(best_s));      // (computed by every lane: no branch around the loads above)
-        if (best_f < tf || best_s < ts) {
-            *reinterpret_cast<tile_f2 *>(const_cast<float *>(vb) + t_off + C) = ZPOS ? tile_f2{best_f, best_s} : tile_f2{best_s, best_f};
-            improved = true;
-        }
-        // roll on to the next pair of the column
-        tzu = best_s; vzu = vs;
-        vp = nv; tp = nt; nv = n_nv; nt = n_nt;
-        vxm = n_vxm; vxp = n_vxp; vym = n_vym; vyp = n_vyp;
-        // the next step reads what this one wrote (other lanes, same wavefront: LDS
-        // operations of a wavefront execute in order; keep the compiler from moving them)
-        __builtin_amdgcn_wave_barrier();
-    }
-#undef FIRST
-#undef SECOND
-#undef LD2
-    return improved;
-}
-
 // NE: entries relaxed (the star, padded with no-ops); EXACT: some entry is live in one
-// direction only, i.e. liveness has to be evaluated; SIX: the star is exactly the six axis
-// neighbours (SIX_DEL).
-template <int NE, bool EXACT, bool SIX>
+// direction only, i.e. liveness has to be evaluated.  (The plain 6-neighbour star has a kernel
+// of its own, tile_six_kernel.)
+template <int NE, bool EXACT>
 __global__ void __launch_bounds__(64)
 tile_sweep_kernel(TileSweep P, const int2 *__restrict__ list, const int *__restrict__ ctrl)
 {
@@ -338,7 +252,7 @@ tile_sweep_kernel(TileSweep P, const int2 *__restrict__ list, const int *__restr
     const DevLayout &L = P.L;
     const int count = ctrl[0];
 
-    const int R = SIX ? 1 : P.R;
+    const int R = P.R;
     const int SY = TILE_Y + 2 * R;
     const int nslots = (TILE_X + 2 * R) * SY * TILE_QPR;
     const int niter = (nslots + 63) >> 6;
@@ -354,7 +268,7 @@ tile_sweep_kernel(TileSweep P, const int2 *__restrict__ list, const int *__restr
     float hh[NE];
 #pragma unroll
     for (int e = 0; e < NE; e++) {
-        del[e] = SIX ? SIX_DEL[e] : (P.ent[e].da * SY + P.ent[e].db) * TILE_PITCH + P.ent[e].dc;
+        del[e] = (P.ent[e].da * SY + P.ent[e].db) * TILE_PITCH + P.ent[e].dc;
         hh[e] = P.ent[e].h;
     }
     const unsigned s0b = (unsigned)(L.s0 * 4), s1b = (unsigned)(L.s1 * 4);
@@ -395,11 +309,10 @@ tile_sweep_kernel(TileSweep P, const int2 *__restrict__ list, const int *__restr
         // z faces, which arrive in registers meanwhile.
         const long long g0 = (long long)(I * TILE_X + L.lo[0] - R) * L.s0
                            + (long long)(J * TILE_Y + L.lo[1] - R) * L.s1 + (K * TILE_Z + L.lo[2] - TILE_ZF);
-        const int FZ = SIX ? 1 : P.fz;
+        const int FZ = P.fz;
         const int nface = (TILE_X + 2 * R) * SY * 2 * FZ;           // face cells around this tile
         const float *const tface = P.tface + (long long)s * P.face_cells;
-        constexpr int NFI = SIX ? ((TILE_X + 2) * (TILE_Y + 2) * 2 + 63) / 64
-                                : ((TILE_X + 2 * TILE_MAX_R) * (TILE_Y + 2 * TILE_MAX_R) * 2 * TILE_ZF + 63) / 64;
+        constexpr int NFI = ((TILE_X + 2 * TILE_MAX_R) * (TILE_Y + 2 * TILE_MAX_R) * 2 * TILE_ZF + 63) / 64;
         float fv[NFI], ft[NFI];
         {
             // (the previous tile's LDS writes have retired before the image is overwritten)
@@ -465,10 +378,6 @@ tile_sweep_kernel(TileSweep P, const int2 *__restrict__ list, const int *__restr
         bool improved = false;
         int kp = -ip - jp;
         int at = row0 + (P.sz > 0 ? kp : TILE_Z - 1 - kp);
-        if constexpr (SIX) {
-            improved = P.sz > 0 ? six_sweep<true>(vimg, nslots * 4, row0, ip + jp, klo, span, P)
-                                : six_sweep<false>(vimg, nslots * 4, row0, ip + jp, klo, span, P);
-        } else
         for (int d = 0; d < TILE_X + TILE_Y + TILE_Z - 2; d++, kp++, at += dat) {
             if ((unsigned)(kp - klo) < span) {
                 float vo[NE], to[NE];
@@ -558,6 +467,236 @@ tile_sweep_kernel(TileSweep P, const int2 *__restrict__ list, const int *__restr
 #endif
 }
 
+// ---------------------------------------------------------------------------
+// The plain 6-neighbour star with a compact image: six tiles in flight per CU instead of five
+// ---------------------------------------------------------------------------
+// The 6-neighbour star reads no corner row and exactly one cell beyond either end of a row, so
+// its image can be dense: 98 rows (the 10 x 10 rows but the first and the last - two corner
+// rows; the other two stay, so that lateral neighbours keep constant offsets) of 32 floats,
+// 8 float4 per row by LDS-DMA, and the rows' two z-halo cells in a table of their own, filled
+// straight from the z faces by 4-byte LDS-DMA.  26 784 bytes with the 128 bytes in front that
+// idle lanes read: 21 of the LDS's 1280-byte granules - six workgroups per CU where the
+// 40-float rows of the general kernel let five fit.
+constexpr int SIXC_NR = (TILE_X + 2) * SIX_SY - 2;          // rows kept
+constexpr int SIXC_PAD = 32;                                // floats in front of the images
+constexpr int SIXC_T = SIXC_NR * TILE_Z;                    // the T rows start here (floats behind the v rows)
+constexpr int SIXC_HV = 2 * SIXC_T;                         // z-halo cells of v: [row][below, above]
+constexpr int SIXC_HT = SIXC_HV + 2 * SIXC_NR;              // ... of T
+constexpr int SIXC_FLOATS = SIXC_PAD + SIXC_HT + 2 * SIXC_NR;
+constexpr int SIXC_NSLOTS = SIXC_NR * (TILE_Z / 4);         // float4 slots of one image
+constexpr int SIXC_NITER = (SIXC_NSLOTS + 63) / 64;
+constexpr int SIXC_NFACE = 2 * SIXC_NR;
+constexpr int SIXC_NFIT = (SIXC_NFACE + 63) / 64;
+
+// The systolic sweep of the plain 6-neighbour star over the compact image (`img` = the v rows,
+// T rows SIXC_T behind, halo cells from the tables; `row` = the lane's image row).  Lane
+// (i', j') owns the z-column (i', j') and relaxes TWO cells per step, k' = 2m and 2m + 1 with
+// m = d - i' - j' (30 steps for 8 x 8 x 32): the first cell's z-upwind neighbour is the lane's
+// own previous result, the second's is the first.  Software-pipelined: of a pair's inputs only
+// the travel times of its four lateral neighbour pairs can have been written in the previous
+// step (by other lanes; two of them really were, which two depends on the ordering); the
+// z-downwind values and all velocities cannot change before this lane is past them.  So a
+// step reads just those four pairs behind the previous step's writes, then - while they are on
+// their way - what the NEXT pair needs that is final already; the delays of the current pair
+// come from values that arrived a step ago.  The dependent chain of a step is one LDS round
+// trip plus about ten vector instructions, for two cells.  A step is also short in
+// instructions: one address register (every input is a compile-time offset from it: ZPOS is
+// the direction along z), 64-bit LDS accesses (a pair is 8-byte aligned), and the lateral
+// relaxations as packed operations over the pair.  Lanes outside their 16 steps run the same
+// instructions on in-image addresses and store nothing.  Entries in the pull star's order:
+// x-, y-, z-, z+, y+, x+.
+template <bool ZPOS>
+__device__ __forceinline__ bool sixc_sweep(float *img, int row, int ij, int klo, unsigned span, const TileSweep &P)
+{
+    static_assert(TILE_Z == 32, "rows are whole 128-byte lines");
+    constexpr int DP = ZPOS ? 2 : -2, DX = SIX_SY * TILE_Z, DY = TILE_Z;
+    constexpr int C = DX + 4;               // index of the current pair from the base below (every index >= -SIXC_PAD)
+    float hxm = P.ent[0].h, hxp = P.ent[5].h, hym = P.ent[1].h, hyp = P.ent[4].h,
+          hzu = P.ent[ZPOS ? 2 : 3].h, hzd = P.ent[ZPOS ? 3 : 2].h;
+    asm volatile("" : "+v"(hxm), "+v"(hxp), "+v"(hym), "+v"(hyp), "+v"(hzu), "+v"(hzd));
+    const tile_f2 hxm2 = {hxm, hxm}, hxp2 = {hxp, hxp}, hym2 = {hym, hym}, hyp2 = {hyp, hyp};
+#define FIRST(p) (ZPOS ? (p).x : (p).y)
+#define SECOND(p) (ZPOS ? (p).y : (p).x)
+#define LD2(i) (*reinterpret_cast<const tile_f2 *>(vb + (i)))
+    // the cells beyond the two ends of this lane's row, in sweep direction
+    const tile_f2 hv = *reinterpret_cast<const tile_f2 *>(img + SIXC_HV + 2 * row);
+    const tile_f2 ht = *reinterpret_cast<const tile_f2 *>(img + SIXC_HT + 2 * row);
+    const float hv_up = ZPOS ? hv.x : hv.y, ht_up = ZPOS ? ht.x : ht.y;
+    const float hv_dn = ZPOS ? hv.y : hv.x, ht_dn = ZPOS ? ht.y : ht.x;
+    int m = -ij;                            // pair of this step: k' = 2m, 2m + 1
+    const float *vb = img + (row * TILE_Z + (ZPOS ? 2 * m : TILE_Z - 2 - 2 * m) - C);
+    tile_f2 vp = LD2(C), tp = LD2(SIXC_T + C);                  // own pair
+    tile_f2 nv = LD2(C + DP), nt = LD2(SIXC_T + C + DP);        // own next pair
+    float vzu = hv_up, tzu = ht_up;                             // own previous cell (set again when m == 0)
+    tile_f2 vxm = LD2(C - DX), vxp = LD2(C + DX), vym = LD2(C - DY), vyp = LD2(C + DY);
+    bool improved = false;
+#pragma unroll 2
+    for (int d = 0; d < TILE_X + TILE_Y + TILE_Z / 2 - 2; d++, m++, vb += DP) {
+        // possibly written in the previous step: asked for first
+        tile_f2 txm = LD2(SIXC_T + C - DX), txp = LD2(SIXC_T + C + DX), tym = LD2(SIXC_T + C - DY), typ = LD2(SIXC_T + C + DY);
+        __builtin_amdgcn_sched_barrier(0);
+        // final already, wanted by the next pair (and the pair after it along the column)
+        const tile_f2 n_vxm = LD2(C + DP - DX), n_vxp = LD2(C + DP + DX), n_vym = LD2(C + DP - DY), n_vyp = LD2(C + DP + DY);
+        tile_f2 n_nv = LD2(C + 2 * DP), n_nt = LD2(SIXC_T + C + 2 * DP);
+        __builtin_amdgcn_sched_barrier(0);
+        // the row ends: the cell before the first pair and the cell behind the last one are halo cells
+        if (m == 0) { vzu = hv_up; tzu = ht_up; }
+        if (m == TILE_Z / 2 - 1) {
+            if (ZPOS) { nv.x = hv_dn; nt.x = ht_dn; } else { nv.y = hv_dn; nt.y = ht_dn; }
+        }
+        // this pair: lateral delays (both cells at once), the column's delays and candidates
+        const tile_f2 lxm = hxm2 * (vp + vxm), lxp = hxp2 * (vp + vxp), lym = hym2 * (vp + vym), lyp = hyp2 * (vp + vyp);
+        const float vf = FIRST(vp), vs = SECOND(vp), tf = FIRST(tp), ts = SECOND(tp);
+        const float sfs = vf + vs;
+        const float czu_f = hzu * (vf + vzu) + tzu;             // first cell from its z-upwind neighbour
+        const float czd_f = hzd * sfs + ts;                     // first from second (old value)
+        const float lzu_s = hzu * sfs;                          // second from first (this step's result)
+        const float czd_s = hzd * (vs + FIRST(nv)) + FIRST(nt); // second from the next pair's first
+        float pre_f = fminf(tf, fminf(czu_f, czd_f)), pre_s = fminf(ts, czd_s);
+        const bool mine_f = (unsigned)(2 * m - klo) < span, mine_s = (unsigned)(2 * m + 1 - klo) < span;
+        asm volatile("" : "+v"(pre_f), "+v"(pre_s), "+v"(txm), "+v"(txp), "+v"(tym), "+v"(typ));
+        const tile_f2 cxm = lxm + txm, cxp = lxp + txp, cym = lym + tym, cyp = lyp + typ;
+        pre_s = fminf(fminf(pre_s, fminf(SECOND(cxm), SECOND(cxp))), fminf(SECOND(cym), SECOND(cyp)));
+        float best_f = fminf(fminf(pre_f, fminf(FIRST(cxm), FIRST(cxp))), fminf(FIRST(cym), FIRST(cyp)));
+        best_f = mine_f ? best_f : tf;
+        float best_s = fminf(pre_s, lzu_s + best_f);
+        best_s = mine_s ? best_s : ts;
+        asm volatile("" : "+v"(best_f), "+v"(best_s));
+        if (best_f < tf || best_s < ts) {
+            *reinterpret_cast<tile_f2 *>(const_cast<float *>(vb) + SIXC_T + C) = ZPOS ? tile_f2{best_f, best_s} : tile_f2{best_s, best_f};
+            improved = true;
+        }
+        tzu = best_s; vzu = vs;
+        vp = nv; tp = nt; nv = n_nv; nt = n_nt;
+        vxm = n_vxm; vxp = n_vxp; vym = n_vym; vyp = n_vyp;
+        __builtin_amdgcn_wave_barrier();
+    }
+#undef FIRST
+#undef SECOND
+#undef LD2
+    return improved;
+}
+
+__global__ void __launch_bounds__(64)
+tile_six_kernel(TileSweep P, const int2 *__restrict__ list, const int *__restrict__ ctrl)
+{
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int lane = threadIdx.x;
+    const DevLayout &L = P.L;
+    const int count = ctrl[0];
+    float *const img = lds + SIXC_PAD;              // v rows; T rows SIXC_T behind; halo tables behind them
+
+    const int ip = lane >> 3, jp = lane & 7;
+    const int ci = P.sx > 0 ? ip : TILE_X - 1 - ip;
+    const int cj = P.sy > 0 ? jp : TILE_Y - 1 - jp;
+    const int row = (ci + 1) * SIX_SY + (cj + 1) - 1;          // this lane's image row
+    const unsigned s0b = (unsigned)(L.s0 * 4), s1b = (unsigned)(L.s1 * 4);
+
+#ifdef TTSWEEP_TILE_PROFILE
+    unsigned long long prof_acc[5] = {};
+#endif
+    PROF_STAMP(t_begin);
+    const int nwg = uni((int)gridDim.x), ntodo = uni(count);
+    int flagged = -1;
+    for (int next = uni((int)blockIdx.x); next < ntodo; next = uni(next + nwg)) {
+        const const_item_ptr ip_ = (const_item_ptr)(list + next);
+        const int s = ip_->s, tile = ip_->tile;
+        PROF_STAMP(t_top);
+        const const_start_ptr sdp = (const_start_ptr)(P.starts + s);
+        float *const T = sdp->T;
+        int2 *const state = reinterpret_cast<int2 *>(sdp->tile_flags);
+        const int K = tile % P.NK, J = (tile / P.NK) % P.NJ, I = tile / (P.NK * P.NJ);
+
+        // ---- stage: rows (x - 1 .. x + 8, y - 1 .. y + 8) but the two corner rows at the ends,
+        // their 32 interior cells each (one 128-byte line), and the rows' z-halo cells from the faces
+        const long long g0 = (long long)(I * TILE_X + L.lo[0] - 1) * L.s0
+                           + (long long)(J * TILE_Y + L.lo[1] - 1) * L.s1 + (K * TILE_Z + L.lo[2]);
+        float *const tface = P.tface + (long long)s * P.face_cells;
+        {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // (the previous tile's LDS traffic has retired)
+            const tile_rsrc rv = tile_make_rsrc(uni_ptr(P.v + g0)), rt = tile_make_rsrc(uni_ptr(T + g0));
+#pragma unroll
+            for (int it = 0; it < SIXC_NITER; it++) {
+                const int sl = it * 64 + lane;
+                if (sl < SIXC_NSLOTS) {
+                    const int r = (sl >> 3) + 1, q = sl & 7;
+                    const int ri = r / SIX_SY, rj = r - ri * SIX_SY;
+                    const unsigned off = (unsigned)ri * s0b + (unsigned)rj * s1b + (unsigned)q * 16u;
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rv, (__attribute__((address_space(3))) void *)(img + it * 256),
+                                                             16, (int)off, 0, 0, 0);
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rt, (__attribute__((address_space(3))) void *)(img + SIXC_T + it * 256),
+                                                             16, (int)off, 0, 0, 0);
+                }
+            }
+            const tile_rsrc fv = tile_make_rsrc(uni_ptr(P.vface)), ft = tile_make_rsrc(uni_ptr(tface));
+#pragma unroll
+            for (int it = 0; it < SIXC_NFIT; it++) {
+                const int f = it * 64 + lane;
+                if (f < SIXC_NFACE) {
+                    const int r = (f >> 1) + 1, side = f & 1;
+                    const int ri = r / SIX_SY, rj = r - ri * SIX_SY;
+                    // below the tile: boundary K, its lower side; above: boundary K + 1, its upper side
+                    const unsigned off = (unsigned)(tile_face_index(L, 1, K + side, side, 0, I * TILE_X + ri, J * TILE_Y + rj) * 4);
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(fv, (__attribute__((address_space(3))) void *)(img + SIXC_HV + it * 64),
+                                                             4, (int)off, 0, 0, 0);
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(ft, (__attribute__((address_space(3))) void *)(img + SIXC_HT + it * 64),
+                                                             4, (int)off, 0, 0, 0);
+                }
+            }
+        }
+        const bool xy_ok = I * TILE_X + ci < L.n[0] && J * TILE_Y + cj < L.n[1];
+        const int z_cells = min(TILE_Z, L.n[2] - K * TILE_Z);
+        const int klo = P.sz > 0 ? 0 : TILE_Z - z_cells;
+        const unsigned span = xy_ok ? (unsigned)z_cells : 0u;
+
+        PROF_STAMP(t_issued);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // the image has landed (one wave: no barrier)
+        PROF_STAMP(t_landed);
+        const bool improved = P.sz > 0 ? sixc_sweep<true>(img, row, ip + jp, klo, span, P)
+                                       : sixc_sweep<false>(img, row, ip + jp, klo, span, P);
+        PROF_STAMP(t_swept);
+
+        // ---- write the tile back if it improved: 64 rows of 8 float4
+        if (__ballot(improved) != 0ull) {
+            const long long t0 = (long long)(I * TILE_X + L.lo[0]) * L.s0 + (long long)(J * TILE_Y + L.lo[1]) * L.s1
+                               + (K * TILE_Z + L.lo[2]);
+#pragma unroll
+            for (int it = 0; it < TILE_X * TILE_Y * (TILE_Z / 4) / 64; it++) {
+                const int r = (it * 64 + lane) >> 3, q = lane & 7;
+                const int ri = r >> 3, rj = r & 7;
+                const float4 val = *reinterpret_cast<const float4 *>(
+                    img + SIXC_T + ((ri + 1) * SIX_SY + (rj + 1) - 1) * TILE_Z + 4 * q);
+                *reinterpret_cast<float4 *>(T + t0 + (long long)ri * L.s0 + (long long)rj * L.s1 + 4 * q) = val;
+            }
+            // this column's first and last cell into the faces of the tile's two boundaries
+            const int pa = I * TILE_X + 1 + ci, pb = J * TILE_Y + 1 + cj;
+            tface[tile_face_index(L, 1, K, 1, 0, pa, pb)] = img[SIXC_T + row * TILE_Z];
+            tface[tile_face_index(L, 1, K + 1, 0, 0, pa, pb)] = img[SIXC_T + row * TILE_Z + TILE_Z - 1];
+            if (lane == 0) state[tile].y = P.epoch;
+            if (s != flagged) {
+                if (lane == 0) atomicOr(&P.changed[s], CHANGED_IMPROVED);
+                flagged = s;
+            }
+        }
+#ifdef TTSWEEP_TILE_PROFILE
+        {
+            const long long t_end = prof_now();
+            prof_acc[0] += (unsigned long long)(t_issued - t_top);
+            prof_acc[1] += (unsigned long long)(t_landed - t_issued);
+            prof_acc[2] += (unsigned long long)(t_swept - t_landed);
+            prof_acc[3] += (unsigned long long)(t_end - t_swept);
+            prof_acc[4] += 1ull;
+        }
+#endif
+    }
+#ifdef TTSWEEP_TILE_PROFILE
+    if (lane == 0 && prof_acc[4]) {
+        for (int i = 0; i < 5; i++) atomicAdd(&g_tile_prof[i], prof_acc[i]);
+        atomicAdd(&g_tile_prof[5], (unsigned long long)(prof_now() - t_begin));
+    }
+#endif
+}
+
 size_t tile_lds_bytes(int R)
 {
     const int nslots = (TILE_X + 2 * R) * (TILE_Y + 2 * R) * TILE_QPR;
@@ -576,10 +715,15 @@ static tile_sweep_fn tile_instance(const TileSweep &P)
     bool is_six = P.nent == 6 && P.R == 1 && !exact;
     for (int e = 0; e < 6 && is_six; e++)
         is_six = P.ent[e].da == six[e][0] && P.ent[e].db == six[e][1] && P.ent[e].dc == six[e][2];
-    if (is_six) return tile_sweep_kernel<6, false, true>;
-    if (P.nent <= 6) return exact ? tile_sweep_kernel<6, true, false> : tile_sweep_kernel<6, false, false>;
-    if (P.nent <= 18) return exact ? tile_sweep_kernel<18, true, false> : tile_sweep_kernel<18, false, false>;
-    return exact ? tile_sweep_kernel<TILE_MAX_ENT, true, false> : tile_sweep_kernel<TILE_MAX_ENT, false, false>;
+    if (is_six) return tile_six_kernel;
+    if (P.nent <= 6) return exact ? tile_sweep_kernel<6, true> : tile_sweep_kernel<6, false>;
+    if (P.nent <= 18) return exact ? tile_sweep_kernel<18, true> : tile_sweep_kernel<18, false>;
+    return exact ? tile_sweep_kernel<TILE_MAX_ENT, true> : tile_sweep_kernel<TILE_MAX_ENT, false>;
+}
+
+static size_t tile_instance_lds(const TileSweep &P)
+{
+    return tile_instance(P) == (tile_sweep_fn)tile_six_kernel ? (size_t)SIXC_FLOATS * sizeof(float) : tile_lds_bytes(P.R);
 }
 
 static bool tile_sweep_ok(const TileSweep &P)
@@ -600,7 +744,7 @@ hipError_t tile_sweep_wgs_per_cu(const TileSweep &P, int *wgs)
     if (!tile_sweep_ok(P)) return hipErrorInvalidValue;
     int n = 0;
     const hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, (const void *)tile_instance(P), 64,
-                                                                      tile_lds_bytes(P.R));
+                                                                      tile_instance_lds(P));
     if (e != hipSuccess) return e;
     *wgs = std::max(n, 1);
     return hipSuccess;
@@ -614,7 +758,7 @@ hipError_t launch_tile_sweep(const TileSweep &P, int2 *list, int *ctrl, int nblo
     if (cand > 0x7fffffffLL) return hipErrorInvalidValue;
     hipLaunchKernelGGL(tile_plan_kernel, dim3((unsigned)((cand + 255) / 256)), dim3(256), 0, st, P, list, ctrl);
     nblocks = (int)std::min<long long>(nblocks, cand);
-    hipLaunchKernelGGL(tile_instance(P), dim3((unsigned)nblocks), dim3(64), tile_lds_bytes(P.R), st, P,
+    hipLaunchKernelGGL(tile_instance(P), dim3((unsigned)nblocks), dim3(64), tile_instance_lds(P), st, P,
                        (const int2 *)list, (const int *)ctrl);
     return hipGetLastError();
 }
