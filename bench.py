@@ -159,9 +159,10 @@ def measure_traffic(args, kernel_patterns):
                     if row["Counter_Name"] != counter:
                         continue
                     name = row["Kernel_Name"]
-                    if any(p in name for p in kernel_patterns):
+                    counted = any(p in name for p in kernel_patterns[0])
+                    if counted or any(p in name for p in kernel_patterns[1]):
                         total += float(row["Counter_Value"])
-                        n += kernel_patterns[0] in name
+                        n += counted
             if n == 0:
                 return None
             sums[counter], launches = total, n
@@ -174,7 +175,7 @@ def measure_traffic(args, kernel_patterns):
     return {"bytes_per_launch": (fetch_b + write_b) / launches, "fetch_bytes_per_launch": fetch_b / launches,
             "write_bytes_per_launch": write_b / launches, "launches_profiled": launches,
             "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE child passes of this run "
-                      "(kernels: " + ", ".join(kernel_patterns) + "; read counter x2, gfx950)"}
+                      "(kernels: " + ", ".join(kernel_patterns[0] + kernel_patterns[1]) + "; read counter x2, gfx950)"}
 
 
 def host_program_end_to_end(P, shape, star, starts, v_host):
@@ -258,7 +259,9 @@ def main():
     nstart = len(starts)
     valu_bound = FLOPS_PER_RELAX * npull / BYTES_PER_CELL_SWEEP > BALANCE_FLOPS_PER_BYTE
     tile_star = npull <= 26 and args.kernel in (0, 3)      # (the library's own choice is read back below)
-    patterns = ["tile_sweep_kernel"] if tile_star else ["sweep_units_kernel", "plan_pass_kernel"]
+    # kernels of one sweep launch: the first group is counted (one per launch), all are summed
+    patterns = ([["tile_six_kernel", "tile_sweep_kernel"], ["tile_plan_kernel"]] if tile_star
+                else [["sweep_units_kernel"], ["plan_pass_kernel"]])
 
     # ---- legs that run other processes on the GPU: before this one initialises it
     traffic = host_e2e = None
@@ -353,7 +356,7 @@ def main():
         gbs = alg_bytes / kern_s / 1e9 if kern_s > 0 else 0.0
         tfl = flops / kern_s / 1e12 if kern_s > 0 else 0.0
         kname = {1: "sweep_cell_kernel", 2: "plan_pass_kernel + sweep_units_kernel (one pass)",
-                 3: "tile_plan_kernel + tile_sweep_kernel (one tile hyperplane of an ordering sweep)"}[st["kernel_variant"]]
+                 3: "tile_plan_kernel + tile_six_kernel / tile_sweep_kernel (one tile hyperplane of an ordering sweep)"}[st["kernel_variant"]]
         common = {"kernel": kname, "launches": int(launches), "avg_launch_ms": st["sweep_kernel_ms"] / launches,
                   "algorithmic_bytes_per_launch": alg_bytes / launches,
                   "algorithmic_flops_per_launch": flops / launches,
