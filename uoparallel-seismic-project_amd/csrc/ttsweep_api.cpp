@@ -694,6 +694,7 @@ static int launch_pass(ttsweep_ctx *ctx, int nactive, int nstart, int *d_changed
         P.sy = (o & 2) ? -1 : 1;
         P.sz = (o & 4) ? -1 : 1;
         P.nent = ctx->tile_nent;
+        P.T0 = ctx->d_T;
         P.state0 = ctx->d_tile_flags;
         P.state_stride = (long long)flag_words(ctx->L);
         P.work0 = ctx->d_work;

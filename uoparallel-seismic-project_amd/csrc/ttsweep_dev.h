@@ -192,6 +192,7 @@ struct TileSweep {
     int D;                  // hyperplane: tiles with I' + J' + K' == D (coordinates in sweep direction)
     int epoch;              // launch number within the solve (>= 2)
     int nent;               // pull entries in use; ent[nent..] are no-ops (h = 0 onto the cell itself)
+    float *T0;              // padded travel-time volume of start 0; start s: + s * L.cells
     int *state0;            // activity words of start 0 (StartDesc::tile_flags); start s: + s * state_stride ints
     long long state_stride; //   (the planner computes a start's addresses instead of loading its descriptor)
     unsigned long long *work0;  // work counters of start 0; start s: + 3 s

@@ -602,9 +602,10 @@ tile_six_kernel(TileSweep P, const int2 *__restrict__ list, const int *__restric
         const const_item_ptr ip_ = (const_item_ptr)(list + next);
         const int s = ip_->s, tile = ip_->tile;
         PROF_STAMP(t_top);
-        const const_start_ptr sdp = (const_start_ptr)(P.starts + s);
-        float *const T = sdp->T;
-        int2 *const state = reinterpret_cast<int2 *>(sdp->tile_flags);
+        // (the start's volume and activity words from the launch arguments: no descriptor load
+        // between the list entry and the first staging instruction)
+        float *const T = P.T0 + (long long)s * L.cells;
+        int2 *const state = reinterpret_cast<int2 *>(P.state0 + (long long)s * P.state_stride);
         const int K = tile % P.NK, J = (tile / P.NK) % P.NJ, I = tile / (P.NK * P.NJ);
 
         // ---- stage: rows (x - 1 .. x + 8, y - 1 .. y + 8) but the two corner rows at the ends,
@@ -730,7 +731,7 @@ static bool tile_sweep_ok(const TileSweep &P)
 {
     static_assert(TILE_ZF == 4, "the z halo of an image row is one float4 on either side");
     return P.R >= 1 && P.R <= TILE_MAX_R && P.nent >= 1 && P.nent <= TILE_MAX_ENT
-        && P.fz >= 1 && P.fz <= TILE_ZF && P.vface && P.tface && P.state0 && P.work0
+        && P.fz >= 1 && P.fz <= TILE_ZF && P.vface && P.tface && P.state0 && P.work0 && P.T0
         && P.L.lo[0] == P.R && P.L.lo[1] == P.R && P.L.lo[2] >= TILE_ZF && P.L.lo[2] % TILE_Z == 0   // whole-line rows
         && P.L.s1 % TILE_Z == 0;
 }
