@@ -132,7 +132,9 @@ def workload_args(args):
     return ["--grid", args.grid, "--star", args.star, "--starts", args.starts,
             "--nstarts", str(args.nstarts), "--kernel", str(args.kernel)] + \
         (["--gate-speed", str(args.gate_speed)] if args.gate_speed is not None else []) + \
-        (["--pair-min-starts", str(args.pair_min_starts)] if args.pair_min_starts is not None else [])
+        (["--pair-min-starts", str(args.pair_min_starts)] if args.pair_min_starts is not None else []) + \
+        (["--prepass", str(args.prepass)] if args.prepass else []) + \
+        (["--lib", args.lib] if args.lib else [])
 
 
 def measure_traffic(args, kernel_patterns):
@@ -214,6 +216,91 @@ def host_program_end_to_end(P, shape, star, starts, v_host):
         shutil.rmtree(d, ignore_errors=True)
 
 
+HBM_REGIME = {"grid": "1024,1024,512", "star": "six", "starts": "111", "nstarts": 14}
+
+
+def hbm_regime_wanted(args):
+    """The default line (the BASELINE metric workload, N = 1) also carries the north star's
+    "HBM-roofline run": BASELINE.json config 5's grid with the 6-neighbour star, one GPU's share
+    (14 of the 111 starts), measured in the same process after the headline."""
+    return (not args.child and not args.no_hbm_regime and args.gpus == 1 and args.grid == "241,241,51"
+            and args.star == "818" and args.starts == "24" and args.nstarts == 0 and args.kernel == 0)
+
+
+def hbm_regime_args(args):
+    a = argparse.Namespace(**vars(args))
+    a.grid, a.star, a.starts, a.nstarts = (HBM_REGIME[k] for k in ("grid", "star", "starts", "nstarts"))
+    a.gate_speed = a.pair_min_starts = None
+    a.prepass = 0
+    return a
+
+
+def hbm_regime(P, torch, dev, dev_index, traffic, with_cpu, steps=2):
+    """six-FS on 1024x1024x512, 14 starts, TILE kernel (ordered 8-ordering Gauss-Seidel tile
+    sweeps): the regime where HBM, not the vector ALUs, binds (24 flops per 12 B).  achieved =
+    12 B x cells of the tiles relaxed / time of the sweep launches (HIP events on the library's
+    stream around every ordering sweep), per launch = one tile hyperplane."""
+    nx, ny, nz = map(int, HBM_REGIME["grid"].split(","))
+    cells = nx * ny * nz
+    offs = P.inputs.read_triples(P.inputs.star_path(HBM_REGIME["star"]))
+    fs = P.inputs.make_fs(offs)
+    starts = P.inputs.scaled_starts(P.inputs.read_triples(P.inputs.starts_path(HBM_REGIME["starts"])), nx, ny, nz)
+    starts = starts[:HBM_REGIME["nstarts"]]
+    t_gen = time.perf_counter()
+    v_dev = P.inputs.velocity_model_device(nx, ny, nz, 20160507, dev)
+    torch.cuda.synchronize()
+    t_gen = time.perf_counter() - t_gen
+    sol = P.TravelTimeSolver((nx, ny, nz), fs, device=dev_index)
+    sol.set_velocity(v_dev)
+    tt = torch.empty((len(starts), nx, ny, nz), dtype=torch.float32, device=dev)
+    sol.solve_device(starts, tt, init=True)                 # warm-up
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        sol.solve_device(starts, tt, init=True)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    sol.set_option(P.OPT_TIMING, 1)
+    sol.solve_device(starts, tt, init=True)
+    st = sol.stats()
+    sol.set_option(P.OPT_TIMING, 0)
+    kern_s = st["sweep_kernel_ms"] / 1e3
+    launches = max(st["launches"], 1)
+    alg = BYTES_PER_CELL_SWEEP * st["cells_relaxed"]
+    gbs = alg / kern_s / 1e9 if kern_s > 0 else 0.0
+    out = {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
+           "traffic": traffic["bytes_per_launch"] if traffic else None,
+           "traffic_source": traffic["source"] if traffic else "not measured in this run",
+           "kernel": "tile_six_kernel (one tile hyperplane of an ordering sweep: plans and relaxes its due tiles)",
+           "launches": int(launches), "avg_launch_ms": st["sweep_kernel_ms"] / launches,
+           "algorithmic_bytes_per_launch": alg / launches,
+           "workload": f"{nx}x{ny}x{nz} synthetic velocity, six-FS (6-neighbour star), {len(starts)} starts "
+                       f"(one GPU's share of start-111), converged multi-start solve",
+           "kernel_variant": st["kernel_variant"], "ms_per_solve": dt * 1e3, "steps": steps,
+           "ordering_sweeps_per_start_mean": st["sweeps_total"] / len(starts),
+           "grid_equivalents_of_tiles_per_start_mean": st["cells_relaxed"] / cells / len(starts),
+           "model_generation_s": round(t_gen, 2)}
+    if with_cpu:
+        # the CPU restatement beside it: ONE reference-order pass of one start on the same grid
+        # (a run to convergence is infeasible: the reference order needs of the order of a
+        # thousand passes here); the model is the one the GPU generated
+        sys.path.insert(0, os.path.join(ROOT, "oracle"))
+        import oracle as O
+        O.build()
+        v_host = v_dev.cpu().numpy()
+        ofs = O.make_star(offs)
+        t_cpu = O.tt_init(v_host.shape, starts[0])
+        t0 = time.perf_counter()
+        O.sweep(v_host, t_cpu, ofs, starts[0])
+        dtc = time.perf_counter() - t0
+        out["cpu_baseline"] = {"value": cells / dtc / 1e6, "unit": "Mcells*sweeps/s", "cores": 1, "kind": "port",
+                               "seconds": round(dtc, 2),
+                               "sample": "ONE reference-order pass of start 0 on the same 1024x1024x512 grid and "
+                                         "six-FS star (single thread, gcc -O3)"}
+    sol.close()
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -227,10 +314,17 @@ def main():
     ap.add_argument("--gate-speed", type=float, default=None, help="schedule knob of the STRIP kernel (cells/pass)")
     ap.add_argument("--pair-min-starts", type=int, default=None,
                     help="schedule knob of the STRIP kernel: units of two planes from this many starts on")
+    ap.add_argument("--prepass", type=int, default=0,
+                    help="schedule knob: relax the first N star entries to convergence first (TTSWEEP_OPT_PREPASS_ENTRIES)")
+    ap.add_argument("--lib", default=None, help="another build of libttsweep.so (A/B builds, tools/exp)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline legs")
     ap.add_argument("--no-traffic", action="store_true", help="skip the rocprofv3 --pmc child passes")
     ap.add_argument("--no-host", action="store_true", help="skip the host-program end-to-end leg")
+    ap.add_argument("--no-hbm-regime", action="store_true",
+                    help="skip the HBM-regime run (six-FS, 1024x1024x512, 14 starts) the default line carries")
     ap.add_argument("--child", action="store_true", help=argparse.SUPPRESS)     # profiled child of measure_traffic
+    ap.add_argument("--gather", default="auto", choices=["auto", "device", "host"],
+                    help="N > 1: where the boxes are gathered (auto: by size, multistart.plan_gather)")
     ap.add_argument("--backend", default="nccl",
                     help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only to rehearse "
                          "the multi-rank path on a box with fewer GPUs than ranks)")
@@ -245,6 +339,8 @@ def main():
 
     import ttsweep_pkg
     P = ttsweep_pkg.load()
+    if args.lib:
+        P._lib.use_library(args.lib)
     nx, ny, nz = map(int, args.grid.split(","))
     cells = nx * ny * nz
     offs = P.inputs.read_triples(P.inputs.star_path(args.star))
@@ -266,8 +362,11 @@ def main():
     # ---- legs that run other processes on the GPU: before this one initialises it
     traffic = host_e2e = None
     v_host = P.inputs.velocity_model(nx, ny, nz, 20160507) if small else None
+    hbm_traffic = None
     if world == 1 and not args.no_traffic:
         traffic = measure_traffic(args, patterns)
+        if hbm_regime_wanted(args):
+            hbm_traffic = measure_traffic(hbm_regime_args(args), [["tile_six_kernel", "tile_sweep_kernel"], []])
     if world == 1 and not args.no_host and small:
         host_e2e = host_program_end_to_end(P, (nx, ny, nz), args.star, starts, v_host)
 
@@ -301,13 +400,28 @@ def main():
     if args.pair_min_starts is not None:
         sol.set_option(P.OPT_PAIR_MIN_STARTS, args.pair_min_starts)
     sol.set_velocity(v_dev)
+    if args.prepass:
+        sol.set_option(P.OPT_PREPASS_ENTRIES, args.prepass)
     tt = torch.empty((len(mine), nx, ny, nz), dtype=torch.float32, device=dev)
+
+    # where the final gather goes: rank 0's device memory while the result set fits a stated
+    # share of what is free there, host memory (one shared array every rank's GPU copies into)
+    # beyond that - config 5's 111 x 2.1 GB do not fit one GPU - and always under the gloo
+    # rehearsal backend, which cannot move device tensors
+    gather = {"path": "none", "why": "one rank"}
+    if dist is not None:
+        plan = [None]
+        if rank == 0:
+            free_dev = torch.cuda.mem_get_info(dev)[0] if args.backend == "nccl" else None
+            plan[0] = P.multistart.plan_gather(nstart, cells * 4, free_dev)
+            if args.gather != "auto":
+                plan[0] = {"path": args.gather, "bytes": nstart * cells * 4, "why": "--gather"}
+        dist.broadcast_object_list(plan, src=0)
+        gather = plan[0]
 
     def step():
         sol.solve_device(my_starts, tt, init=True)
-        if dist is not None and args.backend != "nccl":     # rehearsal: gather through the host
-            return P.multistart.gather_boxes(tt.cpu(), nstart, dist, dst=0, shards=shards)
-        return P.multistart.gather_boxes(tt, nstart, dist, dst=0, shards=shards)
+        return P.multistart.gather_boxes(tt, nstart, dist, dst=0, shards=shards, path=gather["path"])
 
     def fence():
         if dist is not None:
@@ -383,7 +497,9 @@ def main():
                                    f"{nstart} starts (start-{args.starts}), converged multi-start solve",
                        "grid": [nx, ny, nz], "star_offsets": int(len(offs)), "starts": int(nstart),
                        "starts_per_gpu": len(mine), "parallelism": f"starts sharded over {world} GPU(s)",
+                       "gather": gather,
                        "kernel_variant": st["kernel_variant"],
+                       "library": os.path.relpath(P._lib.LIB_PATH, ROOT),
                        "passes_per_start_mean": sweeps_all / args.steps / nstart,
                        "full_sweep_equivalents_per_start_mean": relaxed_all / cells / args.steps / nstart},
             "roofline": valu if valu_bound else hbm,
@@ -418,6 +534,11 @@ def main():
                 tts_["cpu_basis"] = (f"measured seconds per reference-order sweep on this host x the sweeps the "
                                      f"unmodified reference needed (mean {mean_sweeps:.1f} over {len(ref)} of the "
                                      f"{nstart} starts, tests/golden/big_digests.json); one start per core")
+        if hbm_regime_wanted(args) and world == 1:
+            sol.close()
+            del tt, v_dev
+            torch.cuda.empty_cache()
+            out["roofline_hbm_regime"] = hbm_regime(P, torch, dev, dev_index, hbm_traffic, not args.no_cpu)
         print(json.dumps(out), flush=True)
     sol.close()
     if dist is not None:

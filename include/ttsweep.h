@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define TTSWEEP_ABI_VERSION 2
+#define TTSWEEP_ABI_VERSION 3
 
 /* Forward-star entry: same layout as `struct FS`
  * (serial_new/sweep-tt-multistart.c:46-49).  d must already hold
@@ -90,6 +90,13 @@ typedef struct ttsweep_ctx ttsweep_ctx;
 #define TTSWEEP_OPT_GATE_R0_MILLI 6   /* schedule only: gate radius of the first pass, cells x 1/1000
                                          (default: the star's reach + 1) */
 
+#define TTSWEEP_OPT_PREPASS_ENTRIES 8  /* schedule only, never the result: relax the first N entries of
+                                         the star (fs[starstart .. starstart+N-1]) to their own fixed
+                                         point first, then the whole star from that state - the
+                                         pre-processing of old/wavefront-openmp/wave-multistart.c:210-215
+                                         (there: N = fsindex[3], the entries no longer than 4 cells,
+                                         146 of the 818).  0 (default) switches it off. */
+
 #define TTSWEEP_KERNEL_AUTO       0
 #define TTSWEEP_KERNEL_CELL       1   /* one thread per cell, star from global memory */
 #define TTSWEEP_KERNEL_STRIP      2   /* LDS-staged plane slabs, register strips */
@@ -102,6 +109,13 @@ int ttsweep_abi_version(void);
 int ttsweep_device_count(void);
 /* text of the most recent error on this thread ("" if none) */
 const char *ttsweep_last_error(void);
+
+/* Optional: start initialising the HIP runtime for `device` on a background thread and
+ * return at once (ttsweep_create waits for it).  A host program calls it first thing, so
+ * that the few hundred milliseconds a process pays at its first HIP call run beside its
+ * own file reading (serial_new/...:77-147) instead of inside its first sweepXYZ call.
+ * Never needed for correctness.  Returns 0. */
+int ttsweep_warmup(int device);
 
 /* ---- context ----------------------------------------------------------- */
 /* Create a solver for an nx*ny*nz grid and the star entries
@@ -116,7 +130,9 @@ void ttsweep_destroy(ttsweep_ctx *ctx);
 int ttsweep_set_option(ttsweep_ctx *ctx, int key, long long value);
 
 /* Velocity volume (the global `vbox.box.flat`, :65), host or device memory,
- * FLOATBOX layout.  The library keeps its own device copy. */
+ * FLOATBOX layout.  The library keeps its own device copy.  Every value must be finite
+ * and >= 0 (zero is accepted as the reference accepts it; a negative velocity, for which
+ * the reference's loop :151-170 need not terminate, Inf and NaN are refused: < 0). */
 int ttsweep_set_velocity(ttsweep_ctx *ctx, const float *v_host);
 int ttsweep_set_velocity_device(ttsweep_ctx *ctx, const float *v_dev);
 
@@ -127,7 +143,11 @@ int ttsweep_set_velocity_device(ttsweep_ctx *ctx, const float *v_dev);
  *                the initial state and overwritten with the converged state.
  * Returns 1 if any travel time improved, 0 if every box was already converged
  * (the two outcomes `anychange != 0` / `== 0` of :163-166), < 0 on error.
- * Replaces: the whole `while (anychange)` loop of :151-170 over all starts. */
+ * Replaces: the whole `while (anychange)` loop of :151-170 over all starts.
+ * A call with exactly the arrays and starts of the previous successful call on this context,
+ * their contents bit for bit as that call left them (checked with a 64-bit digest of every
+ * box; velocity, star and kernel unchanged), is answered with 0 without any device work: it
+ * is the confirming pass of a reference-style driver loop. */
 int ttsweep_solve(ttsweep_ctx *ctx, int nstart, const ttsweep_start *starts,
                   float *const *tt_host);
 

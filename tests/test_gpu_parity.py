@@ -637,8 +637,8 @@ def test_converged_box_with_one_finite_unit_reports_no_change(P, oracle):
     activity unit, which is exactly the case the distance gate treats as "grown from one
     source".  Units the gate holds back keep the start active but are not improvements: a
     second solve of the converged box must return 0 (a reference-style `while (anychange)`
-    driver would otherwise never terminate), and velocities that are not positive finite
-    numbers are refused."""
+    driver would otherwise never terminate), and velocities that are negative or not finite
+    are refused (zero is accepted, as the reference accepts it: test_zero_velocities_vs_oracle)."""
     rng = np.random.default_rng(5)
     shape = (70, 66, 30)        # z is the only axis that fits a wave: it becomes the lane axis
     v = rng.uniform(0.1, 0.5, size=shape).astype(np.float32)
@@ -654,10 +654,14 @@ def test_converged_box_with_one_finite_unit_reports_no_change(P, oracle):
             tt[start] = 0
             assert sol.solve([start], [tt]) == 1
             assert_bit_equal(tt, want, f"kernel {kernel}")
-            assert sol.solve([start], [tt]) == 0
-            assert sol.solve([start], [tt]) == 0
-            assert_bit_equal(tt, want, f"kernel {kernel}, re-solved")
-            for bad in (0.0, -1.0, np.nan, np.inf):
+            # (copies: a call with the very arrays of the previous one is answered from their
+            # digests, test_confirming_call_is_answered_without_device_work - here the kernels'
+            # own report is wanted)
+            for _ in range(2):
+                again = tt.copy()
+                assert sol.solve([start], [again]) == 0 and sol.stats()["sweeps_total"] > 0
+                assert_bit_equal(again, want, f"kernel {kernel}, re-solved")
+            for bad in (-1.0, -1e-40, np.nan, np.inf, -np.inf):
                 w = v.copy()
                 w[3, 4, 5] = bad
                 with pytest.raises(P.TTSweepError):
@@ -736,3 +740,135 @@ def test_duplicate_and_zero_offsets_in_the_star(P, oracle):
         for kernel in (1, 21, 22):
             (tt,), _, _ = gpu_converge(P, v, P.inputs.make_fs(offs), [start], kernel=kernel)
             assert_bit_equal(tt, want, f"{start} kernel {kernel}")
+
+
+def _boxes(shape, starts):
+    tts = []
+    for st in starts:
+        tt = np.full(shape, np.inf, dtype=np.float32)
+        tt[tuple(st)] = 0
+        tts.append(tt)
+    return tts
+
+
+@pytest.mark.parametrize("kernel", KERNELS + [pytest.param(3, id="tile")])
+def test_denormal_delays_vs_oracle(P, oracle, kernel):
+    """Velocities of 1e-42 .. 1e-30: velocities, delays and travel times partly in the denormal
+    range (< 1.18e-38).  The x86 reference keeps denormals; the kernels are built with
+    -fno-honor-nans -mno-amdgpu-ieee and use v_pk_mul_f32 / v_pk_add_f32 / v_min3_f32: their
+    denormal handling must match bit for bit."""
+    rng = np.random.default_rng(77)
+    shape = (26, 40, 21)
+    v = (10.0 ** rng.uniform(-42.0, -30.0, size=shape)).astype(np.float32)
+    v[3:9, 5:30, 2:15] = np.float32(2e-41)          # a block of denormal velocities (one start inside it)
+    assert (v > 0).all() and (v < np.float32(1.2e-38)).any()
+    offs = P.inputs.read_triples(P.inputs.star_path("six" if kernel == 3 else "5"))
+    starts = np.array([[13, 20, 20], [0, 0, 0], [5, 10, 7]], dtype=np.int32)
+    ofs = oracle.make_star(offs)
+    tts, rc, st = gpu_converge(P, v, P.inputs.make_fs(offs), starts, kernel=kernel)
+    assert rc == 1 and st["kernel_variant"] == (2 if kernel > 20 else kernel)
+    denormal_times = 0
+    for start, tt in zip(starts, tts):
+        want, _, _ = oracle.converge(v, ofs, start, order=1)
+        assert np.isfinite(want).all()
+        denormal_times += int((want[want > 0] < np.float32(1.2e-38)).sum())
+        assert_bit_equal(tt, want, f"kernel {kernel}, start {start}")
+    assert denormal_times > 1000        # (the start inside the block: thousands of denormal travel times)
+
+
+@pytest.mark.parametrize("kernel", KERNELS + [pytest.param(3, id="tile")])
+def test_zero_velocities_vs_oracle(P, oracle, kernel):
+    """A region of zero velocity (zero delays between its cells, both signs of zero): accepted
+    as the reference accepts it (serial_new/sweep-tt-multistart.c:216 has no test), same fixed
+    point bit for bit."""
+    shape = (22, 35, 18)
+    v = P.inputs.velocity_model(*shape, seed=21).copy()
+    v[4:12, 10:25, 3:14] = 0.0
+    v[15:20, 2:8, 0:18] = -0.0
+    offs = P.inputs.read_triples(P.inputs.star_path("six" if kernel == 3 else "818"))
+    starts = np.array([[11, 17, 17], [6, 15, 8], [0, 34, 0]], dtype=np.int32)     # (the second one inside the zero block)
+    ofs = oracle.make_star(offs)
+    tts, rc, _ = gpu_converge(P, v, P.inputs.make_fs(offs), starts, kernel=kernel)
+    assert rc == 1
+    for start, tt in zip(starts, tts):
+        want, _, _ = oracle.converge(v, ofs, start, order=1)
+        assert_bit_equal(tt, want, f"kernel {kernel}, start {start}")
+
+
+@pytest.mark.parametrize("entries", [98, 146, 26])
+def test_prepass_leaves_the_fixed_point_unchanged(P, golden24, entries):
+    """TTSWEEP_OPT_PREPASS_ENTRIES (old/wavefront-openmp/wave-multistart.c:210-215: a short
+    sub-range of the star is swept before the whole one; 146 = that program's fsindex[3] for the
+    818 star, 98 = the entries no longer than 3 cells): the converged boxes are the golden 818
+    boxes bit for bit, for all four start kinds, host and device-resident solves."""
+    import torch
+    offs = golden24.star("818")
+    fs = P.inputs.make_fs(offs)
+    keys = ["818_mid", "818_corner", "818_deadin", "818_deadout"]
+    starts = np.array([golden24.z[f"start_{k}"] for k in keys], dtype=np.int32)
+    with P.TravelTimeSolver(golden24.v.shape, fs) as sol:
+        sol.set_velocity(golden24.v)
+        sol.set_option(P.OPT_PREPASS_ENTRIES, entries)     # (after the velocity: it is handed on)
+        tts = _boxes(golden24.v.shape, starts)
+        assert sol.solve(starts, tts) == 1
+        st = sol.stats()
+        assert st["nstart"] == 4 and st["sweeps_total"] > 8
+        for k, tt in zip(keys, tts):
+            assert_bit_equal(tt, golden24.z[f"tt_{k}"], f"{k} pre-pass {entries}")
+        dev = torch.empty((4,) + golden24.v.shape, dtype=torch.float32, device="cuda:0")
+        assert sol.solve_device(starts, dev, init=True) == 1
+        for n, k in enumerate(keys):
+            assert_bit_equal(dev[n].cpu().numpy(), golden24.z[f"tt_{k}"], f"{k} pre-pass {entries}, device")
+        sol.set_option(P.OPT_PREPASS_ENTRIES, 0)           # off again
+        tts = _boxes(golden24.v.shape, starts)
+        assert sol.solve(starts, tts) == 1
+        for k, tt in zip(keys, tts):
+            assert_bit_equal(tt, golden24.z[f"tt_{k}"], f"{k} after the pre-pass was switched off")
+    with P.TravelTimeSolver(golden24.v.shape, fs) as sol:  # option before the velocity
+        sol.set_option(P.OPT_PREPASS_ENTRIES, entries)
+        sol.set_velocity(golden24.v)
+        tts = _boxes(golden24.v.shape, starts[:2])
+        assert sol.solve(starts[:2], tts) == 1
+        for k, tt in zip(keys[:2], tts):
+            assert_bit_equal(tt, golden24.z[f"tt_{k}"], f"{k} pre-pass {entries}, option first")
+
+
+def test_confirming_call_is_answered_without_device_work(P, golden24):
+    """A reference-style driver calls once more with the boxes it was given back to hear 0
+    (serial_new/sweep-tt-multistart.c:151-170).  ttsweep_solve answers that call from a digest of
+    the boxes - per box, so batched and one-start-at-a-time hosts both profit - and any change
+    to a box, its start or the velocity makes it solve again."""
+    offs = golden24.star("818")
+    fs = P.inputs.make_fs(offs)
+    keys = ["818_mid", "818_corner", "818_deadin"]
+    starts = np.array([golden24.z[f"start_{k}"] for k in keys], dtype=np.int32)
+    with P.TravelTimeSolver(golden24.v.shape, fs) as sol:
+        sol.set_velocity(golden24.v)
+        tts = _boxes(golden24.v.shape, starts)
+        assert sol.solve(starts, tts) == 1 and sol.stats()["sweeps_total"] > 0
+        assert sol.solve(starts, tts) == 0 and sol.stats()["sweeps_total"] == 0     # answered from the digests
+        assert sol.stats()["nstart"] == 3
+        for s in range(3):                                                          # one start at a time, too
+            assert sol.solve(starts[s:s + 1], tts[s:s + 1]) == 0 and sol.stats()["sweeps_total"] == 0
+        for k, tt in zip(keys, tts):
+            assert_bit_equal(tt, golden24.z[f"tt_{k}"], k)
+        # a damaged box is solved again (and repaired) ...
+        tts[1][7, 8, 9] = np.inf
+        assert sol.solve(starts, tts) == 1 and sol.stats()["sweeps_total"] > 0
+        assert_bit_equal(tts[1], golden24.z["tt_818_corner"], "repaired")
+        assert sol.solve(starts, tts) == 0 and sol.stats()["sweeps_total"] == 0
+        # ... a box whose values are too SMALL is not a fixed point of anything this context
+        # wrote: it is solved (nothing can raise a value: the reference cannot either)
+        tts[0][3, 3, 3] = np.float32(0.5) * tts[0][3, 3, 3]
+        rc = sol.solve(starts, tts)
+        assert rc in (0, 1) and sol.stats()["sweeps_total"] > 0
+        # ... as is the same array with another start, and everything after a new velocity
+        tts = _boxes(golden24.v.shape, starts)
+        assert sol.solve(starts, tts) == 1
+        other = starts.copy()
+        other[2] = [1, 2, 3]
+        assert sol.solve(other, tts) in (0, 1) and sol.stats()["sweeps_total"] > 0
+        tts = _boxes(golden24.v.shape, starts)
+        assert sol.solve(starts, tts) == 1
+        sol.set_velocity(golden24.v)
+        assert sol.solve(starts, tts) == 0 and sol.stats()["sweeps_total"] > 0      # really solved: nothing to improve

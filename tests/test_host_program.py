@@ -10,8 +10,6 @@ import pytest
 
 from conftest import ROOT
 
-pytestmark = pytest.mark.gpu
-
 HOST_DIR = os.path.join(ROOT, "uoparallel-seismic-project_amd", "host")
 EXE = os.path.join(HOST_DIR, "sweep-tt-multistart")
 
@@ -23,6 +21,7 @@ def exe(pkg):
     return EXE
 
 
+@pytest.mark.gpu
 def test_host_program_end_to_end(exe, pkg, oracle, tmp_path):
     shape = (30, 26, 14)
     v = pkg.inputs.velocity_model(*shape, seed=8)
@@ -64,6 +63,44 @@ def test_host_program_end_to_end(exe, pkg, oracle, tmp_path):
         assert origin == (1, 1, 1) and np.array_equal(box.view(np.uint32), want.view(np.uint32))
 
 
+def _write_inputs(pkg, tmp_path, shape, nstart, seed=3):
+    v = pkg.inputs.velocity_model(*shape, seed=seed)
+    pkg.inputs.write_vbox(str(tmp_path / "model.vbox"), v)
+    rng = np.random.default_rng(seed)
+    starts = np.stack([rng.integers(0, n, size=nstart) for n in shape], axis=1).astype(np.int32)
+    (tmp_path / "starts.txt").write_text(
+        f"{nstart}\n" + "".join(f"{i} {j} {k}\n" for i, j, k in starts))
+    return v, starts
+
+
+def test_host_program_refuses_more_starts_than_STARTMAX(exe, pkg, tmp_path):
+    """STARTMAX is 128 here (12 in the reference, serial_new/sweep-tt-multistart.c:44, which
+    start-24 and start-111 overflow): 129 starts are refused before anything is allocated or any
+    GPU call is made (runs on the CPU tier)."""
+    _write_inputs(pkg, tmp_path, (12, 10, 8), 129)
+    r = subprocess.run([exe, "model.vbox", pkg.inputs.star_path("3"), "starts.txt"], cwd=tmp_path,
+                       capture_output=True, text=True, timeout=120)
+    assert r.returncode == 1 and "Bad number of starting points" in r.stdout and "maximum 128" in r.stdout
+
+
+@pytest.mark.gpu
+def test_host_program_with_STARTMAX_starts(exe, pkg, oracle, tmp_path):
+    """Exactly STARTMAX = 128 start points go through the host program (static arrays full)."""
+    shape = (12, 10, 8)
+    v, starts = _write_inputs(pkg, tmp_path, shape, 128)
+    star = pkg.inputs.star_path("3")
+    env = dict(os.environ, TTSWEEP_NO_OUTPUT="1", TTSWEEP_BINARY_OUTPUT="tt-")
+    r = subprocess.run([exe, "model.vbox", star, "starts.txt"], cwd=tmp_path, env=env,
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "starting point 127:" in r.stdout and "sweep 2 finished: anychange = 0" in r.stdout
+    fs = oracle.make_star(oracle.read_triples(star))
+    for s in (0, 63, 127):
+        want, _, _ = oracle.converge(v, fs, starts[s], order=1)
+        _, box = pkg.inputs.read_vbox(str(tmp_path / f"tt-{s}.vbox"))
+        assert np.array_equal(box.view(np.uint32), want.view(np.uint32)), s
+
+
 def test_host_program_rejects_bad_input(exe, tmp_path):
     r = subprocess.run([exe], cwd=tmp_path, capture_output=True, text=True)
     assert r.returncode == 1 and "usage" in r.stdout
@@ -72,7 +109,8 @@ def test_host_program_rejects_bad_input(exe, tmp_path):
     assert r.returncode == 1 and "Cannot open velocity model file" in r.stdout
 
 
-def test_bench_prints_one_contract_line(pkg):
+@pytest.mark.gpu
+def test_bench_prints_one_contract_line(pkg, exe):
     """bench.py (the driver's entry point): exactly one JSON line on stdout with the keys of
     the contract, the roofline and (with --no-cpu) no CPU leg; value = cells relaxed / time."""
     import json

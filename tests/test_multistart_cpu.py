@@ -20,7 +20,7 @@ def free_port():
         return s.getsockname()[1]
 
 
-def worker(rank, world, port, nstart, outdir):
+def worker(rank, world, port, nstart, outdir, path="device", balanced=False, one_host=True):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -42,9 +42,14 @@ def worker(rank, world, port, nstart, outdir):
             return torch.empty((0,) + shape, dtype=torch.float32)
         return torch.from_numpy(np.stack(boxes))
 
-    allb, local = P.multistart.solve_sharded(starts, solve_fn, dist, dst=0)
-    assert local.shape[0] == len(P.multistart.shard_starts(nstart, world, rank))
+    if not one_host:            # play "ranks on different machines": CPU tensors over the process group
+        P.multistart._same_host = lambda d: False
+    allb, local = P.multistart.solve_sharded(starts, solve_fn, dist, dst=0, shape=shape if balanced else None,
+                                             path=path)
+    assert local.shape[0] == len(P.multistart.shard_starts(nstart, world, rank, starts if balanced else None,
+                                                           shape if balanced else None))
     if rank == 0:
+        assert not allb.is_cuda and tuple(allb.shape) == (nstart,) + shape
         np.save(os.path.join(outdir, "gathered.npy"), allb.numpy())
         np.save(os.path.join(outdir, "starts.npy"), starts)
     else:
@@ -53,10 +58,17 @@ def worker(rank, world, port, nstart, outdir):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,nstart", [(2, 5), (3, 4), (2, 1)])
-def test_sharded_solve_gathers_in_start_order(tmp_path, oracle, pkg, world, nstart):
+@pytest.mark.parametrize("world,nstart,path,balanced,one_host", [
+    (2, 5, "device", False, True),      # unequal shards (3 + 2), boxes straight into their slots
+    (3, 4, "device", True, True),       # cost-balanced shards (not round-robin), 2 + 1 + 1
+    (2, 1, "device", False, True),      # a rank without any start
+    (2, 5, "host", True, True),         # forced host gather: one shared-memory array all ranks write
+    (3, 7, "host", False, True),
+    (2, 5, "host", False, False),       # host gather between machines: CPU tensors, point to point
+])
+def test_sharded_solve_gathers_in_start_order(tmp_path, oracle, pkg, world, nstart, path, balanced, one_host):
     port = free_port()
-    mp.spawn(worker, args=(world, port, nstart, str(tmp_path)), nprocs=world, join=True)
+    mp.spawn(worker, args=(world, port, nstart, str(tmp_path), path, balanced, one_host), nprocs=world, join=True)
     got = np.load(tmp_path / "gathered.npy")
     starts = np.load(tmp_path / "starts.npy")
     assert got.shape[0] == nstart
@@ -154,3 +166,16 @@ def test_star_slices_partition_the_offsets(pkg):
         assert len(sl) == k and sl[0][0] == 0 and sl[-1][1] == n
         assert all(a[1] == b[0] for a, b in zip(sl, sl[1:]))
         assert max(h - l for l, h in sl) - min(h - l for l, h in sl) <= 1
+
+
+def test_gather_plan_picks_the_path_from_the_sizes(pkg):
+    """Device gather while the result set fits half of the root's free HBM, host beyond
+    (1024x1024x512 x 111 starts = 238 GB cannot be gathered on one 288 GB GPU)."""
+    M = pkg.multistart
+    box241, box1024 = 241 * 241 * 51 * 4, 1024 * 1024 * 512 * 4
+    assert M.plan_gather(24, box241, 280 * 10**9)["path"] == "device"
+    assert M.plan_gather(8, 512 * 512 * 256 * 4, 280 * 10**9)["path"] == "device"
+    big = M.plan_gather(111, box1024, 219 * 10**9)
+    assert big["path"] == "host" and big["bytes"] == 111 * box1024
+    assert M.plan_gather(14, box1024, 219 * 10**9)["path"] == "device"
+    assert M.plan_gather(3, box241, None)["path"] == "host"

@@ -13,8 +13,16 @@ import subprocess
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB_PATH = os.path.join(CSRC, "libttsweep.so")
-if os.environ.get("TTSWEEP_EXPERIMENT_LIB"):        # tools/exp/*: A/B builds of the same sources
-    LIB_PATH = os.path.abspath(os.environ["TTSWEEP_EXPERIMENT_LIB"])
+
+
+def use_library(path: str) -> None:
+    """Load another build of the same sources instead of csrc/libttsweep.so (A/B builds of
+    tools/exp; bench.py --lib).  Must be called before the library is first used; the path in
+    use is reported by bench.py in its output line."""
+    global LIB_PATH
+    if _lib is not None:
+        raise RuntimeError("libttsweep.so is already loaded")
+    LIB_PATH = os.path.abspath(path)
 
 
 class FS(C.Structure):
@@ -46,6 +54,7 @@ SYMBOLS = [
     ("ttsweep_abi_version", C.c_int, []),
     ("ttsweep_device_count", C.c_int, []),
     ("ttsweep_last_error", C.c_char_p, []),
+    ("ttsweep_warmup", C.c_int, [C.c_int]),
     ("ttsweep_create", C.c_void_p, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int]),
     ("ttsweep_destroy", None, [C.c_void_p]),
     ("ttsweep_set_option", C.c_int, [C.c_void_p, C.c_int, C.c_longlong]),
@@ -66,7 +75,7 @@ SYMBOLS = [
 ]
 
 OPT_TIMING, OPT_KERNEL, OPT_MAX_SWEEPS, OPT_MAX_BATCH = 1, 2, 3, 4
-OPT_GATE_SPEED_MILLI, OPT_GATE_R0_MILLI, OPT_PAIR_MIN_STARTS = 5, 6, 7
+OPT_GATE_SPEED_MILLI, OPT_GATE_R0_MILLI, OPT_PAIR_MIN_STARTS, OPT_PREPASS_ENTRIES = 5, 6, 7, 8
 KERNEL_AUTO, KERNEL_CELL, KERNEL_STRIP, KERNEL_TILE = 0, 1, 2, 3
 
 

@@ -1,0 +1,175 @@
+// ttsweep_ctx.h - the solver context behind the opaque `ttsweep_ctx` of include/ttsweep.h and the
+// host-side pieces that work on it.  The host side of libttsweep.so is split by concern:
+//   ttsweep_api.cpp     the C ABI (argument checks, host <-> device staging, multi-device threads)
+//   ttsweep_plan.cpp    what is decided once per context or solve: padded layouts, which kernel
+//                       relaxes a star, the STRIP kernel's items and unit order, capacity
+//   ttsweep_driver.cpp  the driver loop of serial_new/sweep-tt-multistart.c:151-170 (without the
+//                       break, :168-169): passes enqueued one ahead of the convergence test
+// There is no CPU relaxation in any of them: every solve runs HIP kernels or fails.
+#pragma once
+
+#include "../../include/ttsweep.h"
+
+#include <hip/hip_runtime.h>
+
+#include <array>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "pullstar.h"
+#include "ttsweep_dev.h"
+#include "ttsweep_kernels.h"
+
+namespace ttsweep {
+
+// error text of the calling thread (ttsweep_last_error); returns -1
+int set_error(const char *fmt, ...) __attribute__((format(printf, 1, 2)));
+
+} // namespace ttsweep
+
+#define HIPCHK(expr)                                                                   \
+    do {                                                                               \
+        hipError_t e_ = (expr);                                                        \
+        if (e_ != hipSuccess)                                                          \
+            return ttsweep::set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_),    \
+                                      __FILE__, __LINE__);                             \
+    } while (0)
+
+// ---------------------------------------------------------------------------
+// context
+// ---------------------------------------------------------------------------
+// Passes are enqueued one ahead of the convergence test (see ttsweep_solve_device), so the
+// per-start "changed" words exist once per pass in flight.
+constexpr int PASS_SLOTS = 3;
+
+struct ttsweep_ctx {
+    // (types of namespace ttsweep: ttsweep_dev.h)
+    using DevLayout = ttsweep::DevLayout; using CellEntry = ttsweep::CellEntry; using FwdEntry = ttsweep::FwdEntry;
+    using StripItem = ttsweep::StripItem; using StripPlan = ttsweep::StripPlan; using TileEntry = ttsweep::TileEntry;
+    using StartDesc = ttsweep::StartDesc;
+    int device = 0;
+    int nx = 0, ny = 0, nz = 0;
+    hipStream_t stream = nullptr;
+
+    std::vector<ttsweep_pull_entry> pull;   // user-axis pull star
+    int radius = 0;
+    long long relax_per_sweep = 0;
+
+    DevLayout L{};
+    int kernel = TTSWEEP_KERNEL_CELL;
+
+    float *d_v = nullptr;                   // padded velocity
+    bool have_v = false;
+    unsigned long long *d_scratch = nullptr;    // four counters for one-off kernels (velocity check, validator)
+    CellEntry *d_cell_entries = nullptr;
+    int n_cell_entries = 0;
+    FwdEntry *d_fwd_entries = nullptr;      // forward star entries (validator)
+    int n_fwd_entries = 0;
+
+    // STRIP kernel: (da, db) columns of the star, dead-edge boxes
+    // STRIP kernel: the star's items for units of one plane (latency mode, few starts) and of
+    // two planes (throughput mode); `np` is the mode of the solve in progress
+    StripItem *d_strip_items[ttsweep::STRIP_PLANES] = {nullptr, nullptr};
+    StripPlan plans[ttsweep::STRIP_PLANES]{};
+    int np = ttsweep::STRIP_PLANES;
+    int pair_min_starts = -1;               // two-plane units from this many starts on; -1: by the supply of units
+    long long pair_min_units = 80000;       //   (starts x one-plane units of a start; measured crossover)
+    std::vector<std::array<int, 3>> special_offsets;   // device-axis offsets e: cell start - e owns a dead edge
+    bool start_is_special = false;
+    int max_box_cells = 0;                  // of the current solve
+    // STRIP: static work list, entry -> (start, unit), XCD-interleaved (build_worklist)
+    int2 *d_worklist = nullptr;
+    size_t worklist_cap = 0;
+    long long worklist_len = 0;
+    // unit queues of a sparse pass (plan_pass_kernel -> sweep_units_kernel)
+    int4 *d_unitq = nullptr;                // ttsweep::UNITQ_LISTS lists of unitq_cap entries
+    size_t unitq_cap = 0;
+    int *d_unitq_ctrl = nullptr;            // UNITQ_CTRL_WORDS (counts, cursors)
+    int nlists = ttsweep::UNITQ_LISTS;               // unit queues = XCDs of the device (census at create)
+    int unitq_blocks = 0;                   // persistent grid: workgroups the device holds at once
+    std::vector<std::vector<int>> unit_order;       // per start: unit ids, nearest to the start first
+    std::vector<long long> unit_order_key;          // start cell the cached order belongs to
+    // Distance gate (see plan_pass_kernel): radius of the first pass and cells it opens per
+    // pass.  Defaults follow the star's reach: final values spread at about half the reach
+    // per pass (measured, 818-offset star: 3.5 cells/pass gives the shortest solve).
+    double gate_speed = 0.0;                // 0: no gate
+    double gate_r0 = 0.0;
+    // TILE kernel: the star in device axes, halo of the staged image, launch counter
+    TileEntry tile_ent[ttsweep::TILE_MAX_ENT];
+    int tile_nent = 0, tile_R = 1, tile_fz = 1;     // entries, max |da|,|db|, max |dc| of the star
+    float *d_vface = nullptr, *d_tface = nullptr;   // z faces of v and of every start's T (TILE layout)
+    int tile_epoch = 1;
+    int tile_blocks = 0;                    // workgroups of the sweep kernel the device holds at once
+    ttsweep::TileSweep tile_sweep{};        // launch arguments of the solve in progress
+    int *d_tile_flags = nullptr;            // capacity_starts x activity words (flag_words)
+    unsigned long long *d_work = nullptr;   // capacity_starts
+    unsigned long long *h_work = nullptr;   // pinned
+    int pass_index = 0;
+
+    // per-solve pools (grown on demand, reused between solves)
+    float *d_T = nullptr;                   // capacity_starts padded volumes
+    int capacity_starts = 0;
+    StartDesc *d_starts = nullptr;
+    int *d_active = nullptr;
+    int *d_changed = nullptr;
+    StartDesc *h_starts = nullptr;          // pinned
+    int *h_active = nullptr;                // pinned
+    int *h_changed = nullptr;               // pinned
+
+    // ttsweep_solve (host boxes): device staging stack in the caller's layout, kept between calls,
+    // and what successful calls returned since the velocity was set: host array -> (start, digest
+    // of the converged box)
+    float *d_stage = nullptr;
+    size_t stage_cap = 0;                   // boxes
+    struct SolvedBox { ttsweep_start start; unsigned long long digest; };
+    std::unordered_map<const float *, SolvedBox> solved;
+
+    // TTSWEEP_OPT_PREPASS: a context of its own for the sub-star that is relaxed first
+    ttsweep_ctx *pre = nullptr;
+    int prepass_entries = 0;
+    std::vector<ttsweep_fs> fs_copy;        // the caller's star entries [0, starstop)
+    int starstart = 0, starstop = 0;
+
+    // options
+    bool timing = false;
+    long long max_sweeps = 100000;
+    int max_batch = 0;                      // cap on starts per ttsweep_solve batch (0: by memory)
+
+    hipEvent_t ev_solve0 = nullptr, ev_solve1 = nullptr;
+    hipEvent_t ev_flags[PASS_SLOTS] = {nullptr, nullptr, nullptr};     // "changed" words of a pass are on the host
+    std::vector<hipEvent_t> ev_pool;        // pairs around sweep launches
+    size_t ev_used = 0;
+
+    ttsweep_stats stats{};
+};
+
+namespace ttsweep {
+
+inline int ctx_bind(const ttsweep_ctx *ctx)
+{
+    HIPCHK(hipSetDevice(ctx->device));
+    return 0;
+}
+
+// ---- ttsweep_plan.cpp ------------------------------------------------------
+int count_xcds(ttsweep_ctx *ctx);                       // ctx->nlists = XCDs of the device
+int device_xcds(int device, hipStream_t stream, int *out);   // the same, measured once per device and process
+bool kernel_available(const ttsweep_ctx *ctx, int k);   // can kernel variant k relax this star?
+int auto_kernel(const ttsweep_ctx *ctx);                // the variant the library picks for it
+void make_layout(ttsweep_ctx *ctx);                     // padded layout of ctx->kernel
+int upload_star(ttsweep_ctx *ctx);                      // pull star (CELL kernel, dead-edge cells, validator)
+int upload_strip_plan(ttsweep_ctx *ctx);                // the STRIP kernel's items, one- and two-plane units
+void fill_special_box(const ttsweep_ctx *ctx, StartDesc &sd);   // dead-edge box of one start
+size_t flag_words(const DevLayout &L);                  // activity words per start
+int ensure_capacity(ttsweep_ctx *ctx, int nstart);      // per-solve pools for nstart starts
+size_t per_start_device_bytes(const ttsweep_ctx *ctx);  // what ensure_capacity allocates per start
+int build_worklist(ttsweep_ctx *ctx, int nactive);      // STRIP: static unit list of the active starts
+void order_units(const ttsweep_ctx *ctx, const StartDesc &sd, std::vector<int> &order);
+
+// ---- ttsweep_driver.cpp ----------------------------------------------------
+// The driver loop on device-resident boxes; returns 1 / 0 / < 0 like ttsweep_solve_device.
+int solve_device_body(ttsweep_ctx *ctx, int nstart, const ttsweep_start *starts,
+                      float *const *tt_dev, int init);
+
+} // namespace ttsweep

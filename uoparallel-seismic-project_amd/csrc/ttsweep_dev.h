@@ -178,7 +178,8 @@ struct TileEntry {
 };
 
 // Arguments of one launch of tile_sweep_kernel: the tiles of hyperplane D of a sweep with
-// ordering (sx, sy, sz), for every active start.
+// ordering (sx, sy, sz), for every active start.  The grid is `groups` single-wavefront
+// workgroups per active start (workgroup b: start active[b / groups], group b % groups).
 struct TileSweep {
     DevLayout L;
     const float *v;
@@ -186,6 +187,7 @@ struct TileSweep {
     const int *active;      // indices of the active starts
     int *changed;           // "changed" words of this sweep, per start
     int nactive;
+    int groups;             // workgroups per active start
     int NI, NJ, NK;         // tiles along a, b, c
     int R;                  // max |da|, |db| (halo of the staged image along a and b)
     int sx, sy, sz;         // sweep ordering, +1 / -1 per axis

@@ -1,0 +1,340 @@
+// ttsweep_driver.cpp - the driver loop of serial_new/sweep-tt-multistart.c:151-170 without the
+// break (:168-169), i.e. old/sweep-serial/sweep-tt-multistart.c:189-211, on device-resident
+// boxes: passes of the kernel variant in use, enqueued one ahead of the convergence test.
+#include "ttsweep_ctx.h"
+
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+
+namespace ttsweep {
+
+static int timed_event(ttsweep_ctx *ctx, hipEvent_t *out)
+{
+    if (ctx->ev_used == ctx->ev_pool.size()) {
+        hipEvent_t e;
+        HIPCHK(hipEventCreate(&e));
+        ctx->ev_pool.push_back(e);
+    }
+    *out = ctx->ev_pool[ctx->ev_used++];
+    HIPCHK(hipEventRecord(*out, ctx->stream));
+    return 0;
+}
+
+// Squared radius (cells) of the distance gate for the pass about to be launched.
+static float gate_r2(const ttsweep_ctx *ctx)
+{
+    if (ctx->gate_speed <= 0) return 3.0e38f;       // gate disabled
+    const double r = ctx->gate_r0 + ctx->gate_speed * (double)ctx->pass_index;
+    return (float)(r * r);
+}
+
+// ---- one pass of each kernel variant -----------------------------------------------------
+
+// STRIP: plan_pass_kernel + sweep_units_kernel.  The pass's "changed" words arrive in
+// h_changed_slot without a copy command, and d_changed_next is cleared for the pass after this
+// one (UnitPassTail).
+static int launch_pass_strip(ttsweep_ctx *ctx, int nactive, int nstart, int *d_changed, int *h_changed_slot,
+                             int *d_changed_next)
+{
+    const StripPlan &plan = ctx->plans[ctx->np - 1];
+    HIPCHK(launch_plan_pass(ctx->L, ctx->d_starts, ctx->d_worklist, ctx->worklist_len, d_changed,
+                            ctx->d_unitq, (int)ctx->unitq_cap, ctx->nlists, ctx->d_unitq_ctrl,
+                            plan, ctx->pass_index & 1, gate_r2(ctx), ctx->stream));
+    UnitPassTail tail;
+    tail.active = ctx->d_active;
+    tail.nactive = nactive;
+    tail.entries = ctx->d_cell_entries;
+    tail.nentries = ctx->n_cell_entries;
+    tail.max_box_cells = (int)ctx->max_box_cells;
+    tail.nstart = nstart;
+    tail.changed_host = h_changed_slot;
+    tail.changed_next = d_changed_next;
+    HIPCHK(launch_sweep_units(ctx->L, ctx->d_v, ctx->d_starts, ctx->d_unitq, (int)ctx->unitq_cap,
+                              ctx->nlists, ctx->d_unitq_ctrl, ctx->unitq_blocks, d_changed,
+                              ctx->d_strip_items[ctx->np - 1], plan, ctx->pass_index & 1, tail, ctx->stream));
+    return 0;
+}
+
+// TILE: what stays the same for every launch of a solve (filled once per solve).
+static int prepare_tile_sweep(ttsweep_ctx *ctx)
+{
+    TileSweep &P = ctx->tile_sweep;
+    P = TileSweep{};
+    P.L = ctx->L;
+    P.v = ctx->d_v;
+    P.starts = ctx->d_starts;
+    P.active = ctx->d_active;
+    P.NI = tile_count(ctx->L.n[0], TILE_X);
+    P.NJ = tile_count(ctx->L.n[1], TILE_Y);
+    P.NK = tile_count(ctx->L.n[2], TILE_Z);
+    P.R = ctx->tile_R;
+    P.nent = ctx->tile_nent;
+    P.T0 = ctx->d_T;
+    P.state0 = ctx->d_tile_flags;
+    P.state_stride = (long long)flag_words(ctx->L);
+    P.work0 = ctx->d_work;
+    P.fz = ctx->tile_fz;
+    P.vface = ctx->d_vface;
+    P.tface = ctx->d_tface;
+    P.face_cells = tile_face_cells(ctx->L, ctx->tile_fz);
+    P.sx = P.sy = P.sz = 1;
+    P.groups = 1;
+    for (int e = 0; e < TILE_MAX_ENT; e++) P.ent[e] = ctx->tile_ent[e];
+    if (ctx->tile_blocks == 0) {
+        hipDeviceProp_t prop;
+        HIPCHK(hipGetDeviceProperties(&prop, ctx->device));
+        // as many single-wavefront workgroups as the device holds at once
+#ifdef TTSWEEP_TILE_WGS_PER_CU
+        int per_cu = TTSWEEP_TILE_WGS_PER_CU;
+#else
+        int per_cu = 1;
+        HIPCHK(tile_sweep_wgs_per_cu(P, &per_cu));
+#endif
+        ctx->tile_blocks = per_cu * std::max(prop.multiProcessorCount, 1);
+    }
+    return 0;
+}
+
+// TILE: one ordering sweep = the tile hyperplanes in stream order, one launch each (the
+// launch finds its due tiles itself: ttsweep_tile.hip, tile_candidate).
+static int launch_pass_tile(ttsweep_ctx *ctx, int nactive, int *d_changed)
+{
+    TileSweep &P = ctx->tile_sweep;
+    P.changed = d_changed;
+    P.nactive = nactive;
+    // the resident grid, dealt evenly over the active starts (at least one workgroup each)
+    P.groups = std::max(ctx->tile_blocks / std::max(nactive, 1), 1);
+    P.groups = std::min(P.groups, P.NJ * P.NK);         // (no more workgroups than candidates)
+    const int o = ctx->pass_index & 7;                  // the eight orderings in turn
+    P.sx = (o & 1) ? -1 : 1;
+    P.sy = (o & 2) ? -1 : 1;
+    P.sz = (o & 4) ? -1 : 1;
+    const int nsteps = P.NI + P.NJ + P.NK - 2;
+    for (int D = 0; D < nsteps; D++) {
+        P.D = D;
+        P.epoch = ++ctx->tile_epoch;
+        HIPCHK(launch_tile_sweep(P, ctx->stream));
+    }
+    ctx->stats.launches += nsteps - 1;
+    return 0;
+}
+
+// One full-grid pass for the active starts.
+static int launch_pass(ttsweep_ctx *ctx, int nactive, int nstart, int *d_changed, int *h_changed_slot,
+                       int *d_changed_next)
+{
+    hipEvent_t e0, e1;
+    if (ctx->timing && timed_event(ctx, &e0)) return -1;
+    if (ctx->kernel == TTSWEEP_KERNEL_STRIP) {
+        if (launch_pass_strip(ctx, nactive, nstart, d_changed, h_changed_slot, d_changed_next)) return -1;
+    } else if (ctx->kernel == TTSWEEP_KERNEL_TILE) {
+        if (launch_pass_tile(ctx, nactive, d_changed)) return -1;
+    } else {
+        HIPCHK(launch_sweep_cell(ctx->L, ctx->d_v, ctx->d_starts, ctx->d_active, nactive,
+                                 d_changed, ctx->d_cell_entries, ctx->n_cell_entries,
+                                 ctx->stream));
+    }
+    if (ctx->timing && timed_event(ctx, &e1)) return -1;
+    ctx->stats.launches++;
+    ctx->pass_index++;
+    return 0;
+}
+
+int solve_device_body(ttsweep_ctx *ctx, int nstart, const ttsweep_start *starts,
+                             float *const *tt_dev, int init)
+{
+    const DevLayout &L = ctx->L;
+    HIPCHK(hipEventRecord(ctx->ev_solve0, ctx->stream));
+    // units of two planes when there are starts enough to fill the machine with them
+    const bool pairs = ctx->pair_min_starts >= 0
+        ? nstart >= ctx->pair_min_starts
+        : (long long)nstart * strip_units(L, 1) >= ctx->pair_min_units;
+    const int np = pairs ? STRIP_PLANES : 1;
+    if (np != ctx->np) ctx->unit_order_key.assign(ctx->unit_order_key.size(), -1);     // orders belong to the other unit grid
+    ctx->np = np;
+
+    for (int s = 0; s < nstart; s++) {
+        const int u[3] = {starts[s].i, starts[s].j, starts[s].k};
+        StartDesc &sd = ctx->h_starts[s];
+        sd.T = ctx->d_T + (size_t)s * L.cells;
+        sd.sa = u[L.perm[0]];
+        sd.sb = u[L.perm[1]];
+        sd.sc = u[L.perm[2]];
+        sd.sidx = dev_index(L, sd.sa, sd.sb, sd.sc);
+        sd.pad_ = 0;
+        fill_special_box(ctx, sd);
+        {
+            long long vol = 1;
+            for (int d = 0; d < 3; d++) vol *= std::max(sd.box_hi[d] - sd.box_lo[d] + 1, 0);
+            ctx->max_box_cells = std::max<long long>(s == 0 ? 0 : ctx->max_box_cells, vol);
+        }
+        sd.tile_flags = ctx->d_tile_flags + (size_t)s * flag_words(L);
+        sd.work = ctx->d_work + 3 * s;
+        if (init) HIPCHK(launch_init_tt(L, sd.T, sd.sidx, ctx->stream));
+        else HIPCHK(launch_pack(L, tt_dev[s], sd.T, INFINITY, ctx->stream));
+        if (ctx->kernel == TTSWEEP_KERNEL_STRIP)
+            HIPCHK(launch_init_tile_flags(L, sd, /*from_box=*/!init, ctx->stream));
+        if (ctx->kernel == TTSWEEP_KERNEL_TILE) {
+            HIPCHK(launch_init_tile_state(L, sd, /*from_box=*/!init, ctx->stream));
+            float *const faces = ctx->d_tface + (size_t)s * tile_face_cells(L, ctx->tile_fz);
+            if (init) HIPCHK(launch_init_tile_faces(L, faces, ctx->tile_fz, sd.sa, sd.sb, sd.sc, ctx->stream));
+            else HIPCHK(launch_build_tile_faces(L, sd.T, faces, ctx->tile_fz, ctx->stream));
+        }
+        ctx->h_active[s] = s;
+    }
+    if (ctx->kernel == TTSWEEP_KERNEL_STRIP) {
+        // host work while the device initialises the boxes: every start's units, nearest
+        // first (kept from the previous solve when the start point is the same)
+        if ((int)ctx->unit_order.size() < nstart) {
+            ctx->unit_order.resize(nstart);
+            ctx->unit_order_key.resize(nstart, -1);
+        }
+        for (int s = 0; s < nstart; s++) {
+            const StartDesc &sd = ctx->h_starts[s];
+            if (ctx->unit_order_key[s] == sd.sidx && !ctx->unit_order[s].empty()) continue;
+            order_units(ctx, sd, ctx->unit_order[s]);
+            ctx->unit_order_key[s] = sd.sidx;
+        }
+    }
+    HIPCHK(hipMemcpyAsync(ctx->d_starts, ctx->h_starts, nstart * sizeof(StartDesc),
+                          hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(hipMemcpyAsync(ctx->d_active, ctx->h_active, nstart * sizeof(int),
+                          hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(hipMemsetAsync(ctx->d_work, 0, 3 * nstart * sizeof(unsigned long long), ctx->stream));
+    ctx->pass_index = 0;
+    ctx->tile_epoch = 1;
+    if (ctx->kernel == TTSWEEP_KERNEL_TILE && prepare_tile_sweep(ctx)) return -1;
+    if (ctx->kernel == TTSWEEP_KERNEL_STRIP) {
+        if (build_worklist(ctx, nstart)) return -1;
+        // the passes keep these cleared themselves from here on
+        HIPCHK(hipMemsetAsync(ctx->d_changed, 0, (size_t)PASS_SLOTS * nstart * sizeof(int), ctx->stream));
+        HIPCHK(hipMemsetAsync(ctx->d_unitq_ctrl, 0, (UNITQ_CTRL_WORDS + 1) * sizeof(int), ctx->stream));
+    }
+
+    // driver loop: serial_new/...:151-170 without the break (:168-169).  Passes are
+    // enqueued ONE AHEAD of the convergence test: pass k+1 is already running while the
+    // host waits for the "changed" words of pass k, so the GPU never idles between
+    // passes.  A start whose pass-k words show no change is converged; the pass k+1
+    // that was launched speculatively for it finds all its units inactive.
+    std::vector<int> sweeps(nstart, 0);
+    std::vector<char> done(nstart, 0);          // converged: the pass launched one ahead for it is not counted
+#ifdef TTSWEEP_DEBUG_ENV
+    const bool trace = getenv("TTSWEEP_TRACE") != nullptr;
+#else
+    const bool trace = false;
+#endif
+    unsigned long long trace_prev = 0, trace_prev_un = 0;
+    std::vector<int> snapshot[PASS_SLOTS];      // active starts of each pass in flight
+    int nactive = nstart, launched = 0, processed = 0;
+    bool anychange_ever = false;
+    auto t_pass = std::chrono::steady_clock::now();
+    while (processed < launched || nactive > 0) {
+        if (nactive > 0 && launched - processed < 2) {          // enqueue the next pass
+            const int slot = launched % PASS_SLOTS;
+            int *dch = ctx->d_changed + (size_t)slot * nstart;
+            int *hch_slot = ctx->h_changed + (size_t)slot * nstart;
+            const bool strip = ctx->kernel == TTSWEEP_KERNEL_STRIP;
+            if (!strip) HIPCHK(hipMemsetAsync(dch, 0, nstart * sizeof(int), ctx->stream));
+            const auto t_enq = std::chrono::steady_clock::now();
+            if (launch_pass(ctx, nactive, nstart, dch, hch_slot,
+                            ctx->d_changed + (size_t)((launched + 1) % PASS_SLOTS) * nstart))
+                return -1;
+            if (trace)
+                fprintf(stderr, "   (host: %.0f us to enqueue pass %d)\n",
+                        std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_enq).count(),
+                        launched + 1);
+            if (!strip)
+                HIPCHK(hipMemcpyAsync(hch_slot, dch, nstart * sizeof(int), hipMemcpyDeviceToHost,
+                                      ctx->stream));
+            HIPCHK(hipEventRecord(ctx->ev_flags[slot], ctx->stream));
+            snapshot[slot].assign(ctx->h_active, ctx->h_active + nactive);
+            launched++;
+            if (launched - processed < 2 && nactive > 0 && launched == 1) continue;   // prime the pipeline
+        }
+        // examine the oldest pass in flight
+        const int slot = processed % PASS_SLOTS;
+        HIPCHK(hipEventSynchronize(ctx->ev_flags[slot]));
+        const int *hch = ctx->h_changed + (size_t)slot * nstart;
+        if (trace) {    // TTSWEEP_TRACE=1: per-pass activity on stderr (serialises the passes)
+            HIPCHK(hipStreamSynchronize(ctx->stream));
+            HIPCHK(hipMemcpy(ctx->h_work, ctx->d_work, 3 * nstart * sizeof(unsigned long long),
+                             hipMemcpyDeviceToHost));
+            unsigned long long tot = 0, un = 0;
+            for (int s = 0; s < nstart; s++) { tot += ctx->h_work[3 * s]; un += ctx->h_work[3 * s + 2]; }
+            const double us = std::chrono::duration<double, std::micro>(
+                                  std::chrono::steady_clock::now() - t_pass).count();
+            t_pass = std::chrono::steady_clock::now();
+            fprintf(stderr, "ttsweep pass %d: %d active starts, %.3f full-sweep equivalents relaxed, "
+                    "%llu units, %.0f us\n", processed + 1, (int)snapshot[slot].size(),
+                    (double)(tot - trace_prev) / (double)ctx->stats.cells
+                        / (double)std::max<size_t>(ctx->pull.size(), 1),
+                    un - trace_prev_un, us);
+            trace_prev = tot;
+            trace_prev_un = un;
+        }
+        bool dropped = false;
+        for (int s : snapshot[slot]) {
+            if (done[s]) continue;
+            sweeps[s]++;
+            if (hch[s]) {           // improved, or units still held back by the gate
+                if (hch[s] & CHANGED_IMPROVED) anychange_ever = true;
+                if (sweeps[s] >= ctx->max_sweeps)
+                    return set_error("start %d did not converge in %lld sweeps", s, ctx->max_sweeps);
+            } else {
+                // converged: remove it from the active list
+                done[s] = 1;
+                int *end = std::remove(ctx->h_active, ctx->h_active + nactive, s);
+                if (end != ctx->h_active + nactive) dropped = true;
+                nactive = (int)(end - ctx->h_active);
+            }
+        }
+        processed++;
+        if (dropped && nactive > 0) {
+            // (the uploads are stream-ordered behind the pass in flight; the stream is
+            // synchronised before h_active is touched again)
+            HIPCHK(hipMemcpyAsync(ctx->d_active, ctx->h_active, nactive * sizeof(int),
+                                  hipMemcpyHostToDevice, ctx->stream));
+            if (ctx->kernel == TTSWEEP_KERNEL_STRIP) {
+                if (build_worklist(ctx, nactive)) return -1;
+            } else {
+                HIPCHK(hipStreamSynchronize(ctx->stream));
+            }
+        }
+    }
+
+    for (int s = 0; s < nstart; s++)
+        HIPCHK(launch_unpack(L, ctx->h_starts[s].T, tt_dev[s], ctx->stream));
+    HIPCHK(hipMemcpyAsync(ctx->h_work, ctx->d_work, 3 * nstart * sizeof(unsigned long long),
+                          hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipEventRecord(ctx->ev_solve1, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+
+#ifdef TTSWEEP_PROFILE
+    prof_dump();
+#endif
+#ifdef TTSWEEP_TILE_PROFILE
+    if (ctx->kernel == TTSWEEP_KERNEL_TILE) tile_prof_dump();
+#endif
+    float ms = 0;
+    HIPCHK(hipEventElapsedTime(&ms, ctx->ev_solve0, ctx->ev_solve1));
+    ctx->stats.solve_ms = ms;
+    for (size_t e = 0; e + 1 < ctx->ev_used; e += 2) {
+        HIPCHK(hipEventElapsedTime(&ms, ctx->ev_pool[e], ctx->ev_pool[e + 1]));
+        ctx->stats.sweep_kernel_ms += ms;
+    }
+    for (int s = 0; s < nstart; s++) {
+        ctx->stats.sweeps_total += sweeps[s];
+        ctx->stats.sweeps_max = std::max(ctx->stats.sweeps_max, sweeps[s]);
+        // CELL kernel relaxes every cell in every pass; STRIP counts its active tiles
+        // (STRIP counts cells x offsets actually relaxed; convert to whole-star cell relaxations)
+        ctx->stats.cells_relaxed += ctx->kernel != TTSWEEP_KERNEL_CELL
+            ? (long long)(ctx->h_work[3 * s] / std::max<size_t>(ctx->pull.size(), 1))
+            : (long long)sweeps[s] * ctx->stats.cells;
+    }
+    return anychange_ever ? 1 : 0;
+}
+
+} // namespace ttsweep

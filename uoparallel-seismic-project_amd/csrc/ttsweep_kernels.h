@@ -20,7 +20,7 @@ hipError_t launch_init_tt(const DevLayout &L, float *padded, long long sidx,
 // ---- device census / input check -------------------------------------------
 // *seen |= 1 << (XCD id) for every workgroup of an `nblocks`-workgroup launch
 hipError_t launch_xcc_census(unsigned *seen, int nblocks, hipStream_t st);
-// *bad += cells of the caller's n-cell velocity volume that are not positive and finite
+// *bad += cells of the caller's n-cell velocity volume that are negative or not finite
 hipError_t launch_count_bad_velocity(const float *v, long long n, unsigned long long *bad, hipStream_t st);
 
 // ---- sweep, variant CELL ---------------------------------------------------
@@ -69,14 +69,14 @@ hipError_t launch_init_tile_flags(const DevLayout &L, const StartDesc &sd, bool 
                                   hipStream_t st);
 
 // ---- sweep, variant TILE ---------------------------------------------------
-// One call = the tiles of one hyperplane of an ordering sweep (TileSweep): tile_plan_kernel
-// lists the due ones - a tile is relaxed only if one of its 27 neighbours improved since it
-// was last relaxed (StartDesc::tile_flags holds two words per tile) - in `list` (room for
-// NJ * NK * nactive entries), counts them in ctrl[0] (zero before the call) and adds their
-// relaxations to the starts' work counters; tile_sweep_kernel (`nblocks` persistent
-// single-wavefront workgroups, at most what tile_sweep_wgs_per_cu says the device holds at
-// once) relaxes entries b, b + nblocks, ...  A sweep = the calls D = 0 .. NI + NJ + NK - 3 in
-// stream order.  changed[s] |= 1 when a tile of start s improved: a whole sweep without a
+// One call = the tiles of one hyperplane of an ordering sweep (TileSweep), ONE kernel: a grid of
+// P.groups single-wavefront workgroups per active start (in all at most what
+// tile_sweep_wgs_per_cu says the device holds at once, unless there are more starts than that);
+// workgroup (start, g) evaluates the candidates g, g + groups, ... of its start - a tile is
+// relaxed only if one of its 27 neighbours improved since it was last relaxed
+// (StartDesc::tile_flags holds two words per tile) - and relaxes the due ones; the starts' work
+// counters get one pair of atomics per workgroup.  A sweep = the calls D = 0 .. NI + NJ + NK - 3
+// in stream order.  changed[s] |= 1 when a tile of start s improved: a whole sweep without a
 // change proves convergence.
 size_t tile_lds_bytes(int R);
 // faces[...] = the z faces (ttsweep_dev.h: tile_face_index) of a padded volume
@@ -84,7 +84,7 @@ hipError_t launch_build_tile_faces(const DevLayout &L, const float *padded, floa
 // the faces of an initialised box (+INFINITY everywhere, 0 at the start cell (sa, sb, sc))
 hipError_t launch_init_tile_faces(const DevLayout &L, float *faces, int fz, int sa, int sb, int sc, hipStream_t st);
 hipError_t tile_sweep_wgs_per_cu(const TileSweep &P, int *wgs);
-hipError_t launch_tile_sweep(const TileSweep &P, int2 *list, int *ctrl, int nblocks, hipStream_t st);
+hipError_t launch_tile_sweep(const TileSweep &P, hipStream_t st);
 // from_box = false: only the start's tile counts as changed; true: every tile does.
 hipError_t launch_init_tile_state(const DevLayout &L, const StartDesc &sd, bool from_box, hipStream_t st);
 

@@ -166,17 +166,17 @@ hipError_t launch_xcc_census(unsigned *seen, int nblocks, hipStream_t st)
     return hipGetLastError();
 }
 
-// Cells of the caller's velocity volume that are not positive finite numbers (the
-// relaxation assumes positive delays; a NaN would also defeat the
-// kernels' NaN-free arithmetic mode).  Integer test on the bit pattern: this file is
-// compiled with -fno-honor-nans.
+// Cells of the caller's velocity volume that are negative, infinite or NaN (the relaxation
+// needs delays >= 0; a NaN would also defeat the kernels' NaN-free
+// arithmetic mode; zero - either sign - is accepted as the reference accepts it).  Integer
+// test on the bit pattern: this file is compiled with -fno-honor-nans.
 __global__ void __launch_bounds__(256)
 count_bad_velocity_kernel(const float *__restrict__ v, long long n, unsigned long long *__restrict__ bad)
 {
     unsigned mine = 0;
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
         const unsigned bits = __float_as_uint(v[i]);
-        mine += !(bits > 0u && bits < 0x7f800000u);
+        mine += !(bits < 0x7f800000u || bits == 0x80000000u);
     }
 #pragma unroll
     for (int w = 32; w >= 1; w >>= 1) mine += __shfl_xor(mine, w);
@@ -415,6 +415,20 @@ constexpr int SLAB_BYTES = 2 * SLAB_T_BYTES;
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// Scalars an item's relaxation needs besides its window: the offset lengths of either own
+// plane (one s_load_dwordx16 each) and the next item's header.  They are handed to the window
+// load, whose "all loads issued" point (an empty asm statement) takes them as inputs: the scalar
+// loads are then issued BEFORE that point and travel beside the window's LDS reads.  (LDS and
+// scalar loads share the lgkmcnt counter and scalar loads return out of order, so the one that
+// is issued second is waited for with lgkmcnt(0) anyway; left to the scheduler, the scalar loads
+// came behind the window's wait and their latency was paid a second time, every item.)
+struct ItemScalars {
+    f32x16 h0, h1;
+    int next_rowoff;
+    unsigned next_m0, next_m1;
+};
 
 // Read-only tables written before the launch (items of the star, start descriptors, the
 // queues the planner filled) are read through the scalar cache: uniform addresses in the
@@ -523,7 +537,7 @@ __host__ __device__ constexpr unsigned window_chunks(unsigned mask)
 // compile-time distance behind the v row.  CHUNKS: the float4s that are needed (others stand
 // in for a loaded one: no instructions).
 template <int K, unsigned CHUNKS>
-__device__ __forceinline__ void load_window(const char *prow, unsigned swb,
+__device__ __forceinline__ void load_window(const char *prow, unsigned swb, const ItemScalars &sc,
                                             f32x2 (&vN2)[(K + 2 * STRIP_CF) / 2], f32x2 (&tN2)[(K + 2 * STRIP_CF) / 2])
 {
     constexpr int W = K + 2 * STRIP_CF;
@@ -543,9 +557,16 @@ __device__ __forceinline__ void load_window(const char *prow, unsigned swb,
         if (!(CHUNKS & (1u << jj))) { xw[jj] = xw[JF]; yw[jj] = yw[JF]; }
     // All loads are issued before the first value is used, and whole float4s are kept: partly
     // used chunks would otherwise be narrowed to ds_read2_b64 pairs (8 LDS cycles instead of 4).
+#ifdef TTSWEEP_NO_SLOAD_PIN
     asm volatile("" :: "v"(xw[0]), "v"(xw[1]), "v"(xw[2]), "v"(xw[3]), "v"(xw[4]), "v"(xw[5]),
                  "v"(xw[6]), "v"(xw[7]), "v"(yw[0]), "v"(yw[1]), "v"(yw[2]), "v"(yw[3]), "v"(yw[4]),
                  "v"(yw[5]), "v"(yw[6]), "v"(yw[7]));
+#else
+    asm volatile("" :: "v"(xw[0]), "v"(xw[1]), "v"(xw[2]), "v"(xw[3]), "v"(xw[4]), "v"(xw[5]),
+                 "v"(xw[6]), "v"(xw[7]), "v"(yw[0]), "v"(yw[1]), "v"(yw[2]), "v"(yw[3]), "v"(yw[4]),
+                 "v"(yw[5]), "v"(yw[6]), "v"(yw[7]), "s"(sc.h0), "s"(sc.h1), "s"(sc.next_rowoff),
+                 "s"(sc.next_m0), "s"(sc.next_m1));
+#endif
 #pragma unroll
     for (int jj = 0; jj < W / 4; jj++) {
         vN2[2 * jj] = f32x2{xw[jj].x, xw[jj].y}; vN2[2 * jj + 1] = f32x2{xw[jj].z, xw[jj].w};
@@ -557,6 +578,7 @@ __device__ __forceinline__ void load_window(const char *prow, unsigned swb,
 // the float4s the set reads are loaded.
 template <int K>
 __device__ __forceinline__ void relax_item_single(unsigned mask, const float (&h)[16], const char *prow, unsigned swb,
+                                                  const ItemScalars &sc,
                                                   const f32x2 (&vce)[K / 2], const f32x2 (&vco)[K / 2 - 1],
                                                   float (&acc)[K])
 {
@@ -564,10 +586,10 @@ __device__ __forceinline__ void relax_item_single(unsigned mask, const float (&h
     switch (mask) {
     case 0u: break;
 #define STRIP_MASK_CASE(m) \
-    case m: load_window<K, window_chunks<K>(m)>(prow, swb, vN2, tN2); relax_window<K, m>(mask, h, vN2, tN2, vce, vco, acc); break;
+    case m: load_window<K, window_chunks<K>(m)>(prow, swb, sc, vN2, tN2); relax_window<K, m>(mask, h, vN2, tN2, vce, vco, acc); break;
 #include "strip_masks.inc"
 #undef STRIP_MASK_CASE
-    default: load_window<K, 0xffu>(prow, swb, vN2, tN2); relax_window<K, 0u>(mask, h, vN2, tN2, vce, vco, acc); break;
+    default: load_window<K, 0xffu>(prow, swb, sc, vN2, tN2); relax_window<K, 0u>(mask, h, vN2, tN2, vce, vco, acc); break;
     }
 }
 
@@ -914,6 +936,9 @@ void prof_dump()
 #define PROF_T(x)
 #endif
 
+#ifndef TTSWEEP_SLABS
+#define TTSWEEP_SLABS 2             // slabs in LDS: 2 = the next plane loads while this one is relaxed; 3 = the next two
+#endif
 #ifndef TTSWEEP_WGS_PER_CU
 #define TTSWEEP_WGS_PER_CU 2        // persistent workgroups per CU (measured optimum)
 #endif
@@ -1063,6 +1088,17 @@ sweep_units_kernel(DevLayout L, const float *__restrict__ v, const StartDesc *__
 #pragma unroll
             for (int p = 0; p < K / 2 - 1; p++) vco[jp][p] = f32x2{vce[jp][p].y, vce[jp][p + 1].x};
         }
+#if TTSWEEP_SLABS == 3
+        // (three slabs: the plane after the first one starts to load as well - behind the own
+        // cells' loads, so that the first wait below, which lets this wave's newest LDS-DMA
+        // instructions stay in flight, does not wait for it)
+        if (todo & (todo - 1)) {
+            const long long src = src0 + (long long)__builtin_ctz(todo & (todo - 1)) * L.s0;
+            stage_slab(v + src, T + src, s1_bytes, slabs + slab_floats, rows, rows8, wave, lane);
+        }
+        // LDS-DMA instructions this wave issues per slab (stage_slab: groups wave, wave + NS, ... of both arrays)
+        const int my_dma = rows8 / 8 > wave ? 2 * ((rows8 / 8 - wave + NS - 1) / NS) : 0;
+#endif
         // what this wave will finish and store at the end: CQ consecutive cells of one own
         // plane; their values before this unit's relaxation stay in registers
         constexpr int CQ = NP * K / NS;     // cells per wave in the epilogue
@@ -1087,6 +1123,23 @@ sweep_units_kernel(DevLayout L, const float *__restrict__ v, const StartDesc *__
             const int next_first = todo
                 ? min(__builtin_amdgcn_readfirstlane(item_range[wave * 16 + __builtin_ctz(todo)]) & 0xffff, nitems - 1)
                 : 0;
+#if TTSWEEP_SLABS == 3
+            // this wave's part of slab `p` has landed (the loads of the plane after it, issued
+            // later, may still be in flight: loads complete in order) ...
+            if (todo == 0 || my_dma == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            else if (my_dma == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+            else if (my_dma == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            else if (my_dma == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            // ... and so has everybody else's; the slab of the previous plane is no longer read
+            __syncthreads();
+            PROF_T(t1);
+            // the plane after the next one loads into that slab while this one is relaxed
+            if (todo & (todo - 1)) {
+                const long long src = src0 + (long long)__builtin_ctz(todo & (todo - 1)) * L.s0;
+                stage_slab(v + src, T + src, s1_bytes, slabs + ((buf + 2) % 3) * slab_floats, rows, rows8, wave, lane);
+            }
+#else
             // this wave's part of slab `p` has landed ...
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             // ... and so has everybody else's; the other slab is no longer read
@@ -1097,6 +1150,7 @@ sweep_units_kernel(DevLayout L, const float *__restrict__ v, const StartDesc *__
                 const long long src = src0 + (long long)__builtin_ctz(todo) * L.s0;
                 stage_slab(v + src, T + src, s1_bytes, slabs + (buf ^ 1) * slab_floats, rows, rows8, wave, lane);
             }
+#endif
             PROF_T(t2);
 #ifdef TTSWEEP_PROFILE
             p_wait += t1 - t0; p_stage += t2 - t1;
@@ -1106,28 +1160,37 @@ sweep_units_kernel(DevLayout L, const float *__restrict__ v, const StartDesc *__
             for (int ii = ibeg; ii < iend; ii++) {
                 const const_item_ptr item = (const_item_ptr)(items + ii);
                 // this item's offset lengths and the next item's header travel while the
-                // window is being read
+                // window is being read (ItemScalars)
                 const ItemHdr nxt = load_hdr(items, ii + 1 < iend ? ii + 1 : next_first);
+                typedef const __attribute__((address_space(4))) f32x16 *const_h_ptr;
+                ItemScalars sc;
+                sc.h0 = *reinterpret_cast<const_h_ptr>(&item->h[0][0]);
+                sc.h1 = NP > 1 ? *reinterpret_cast<const_h_ptr>(&item->h[1][0]) : sc.h0;
+                sc.next_rowoff = nxt.rowoff; sc.next_m0 = nxt.m0; sc.next_m1 = nxt.m1;
                 float h0[16], h1[16];
 #pragma unroll
-                for (int t = 1; t < 16; t++) { h0[t] = item->h[0][t]; h1[t] = NP > 1 ? item->h[1][t] : 0.0f; }
+                for (int t = 1; t < 16; t++) { h0[t] = sc.h0[t]; h1[t] = sc.h1[t]; }
                 const int rowoff = cur.rowoff;
                 const unsigned m0 = cur.m0, m1 = cur.m1;
                 const int row = lane_r + rb + rowoff;
                 const char *prow = reinterpret_cast<const char *>(sv) + row * (STRIP_W * 4);
                 const unsigned swb = (unsigned)slab_swizzle(row) << 4;
                 if (NP == 1) {
-                    relax_item_single<K>(m0, h0, prow, swb, vce[0], vco[0], acc[0]);
+                    relax_item_single<K>(m0, h0, prow, swb, sc, vce[0], vco[0], acc[0]);
                 } else {
                     f32x2 vN2[W / 2], tN2[W / 2];       // window element w is pair w/2, half w&1
-                    load_window<K, 0xffu>(prow, swb, vN2, tN2);
+                    load_window<K, 0xffu>(prow, swb, sc, vN2, tN2);
                     relax_dispatch<K>(m0, h0, vN2, tN2, vce[0], vco[0], acc[0]);
                     relax_dispatch<K>(m1, h1, vN2, tN2, vce[NP - 1], vco[NP - 1], acc[NP - 1]);
                 }
                 cur = nxt;
             }
             if (ibeg >= iend) cur = load_hdr(items, next_first);    // (no item of this plane was ours)
+#if TTSWEEP_SLABS == 3
+            buf = buf == 2 ? 0 : buf + 1;
+#else
             buf ^= 1;
+#endif
 #ifdef TTSWEEP_PROFILE
             p_comp += clock64() - t2;
 #endif
@@ -1226,7 +1289,7 @@ sweep_units_kernel(DevLayout L, const float *__restrict__ v, const StartDesc *__
 size_t units_lds_bytes(const StripPlan &plan, int nb)
 {
     (void)plan; (void)nb;
-    size_t floats = (size_t)2 * SLAB_BYTES / 4;                             // two slabs of v and T rows
+    size_t floats = (size_t)TTSWEEP_SLABS * SLAB_BYTES / 4;                 // the slabs of v and T rows
     floats = std::max(floats, (size_t)STRIP_NS * STRIP_PLANES * STRIP_K * STRIP_TB);    // combine buffer
     return (floats + STRIP_LDS_HEAD) * sizeof(float);
 }

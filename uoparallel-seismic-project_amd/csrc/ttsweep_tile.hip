@@ -12,11 +12,11 @@
 // parallelised over hyperplanes at two levels:
 //   * the grid is cut into tiles of 8 x 8 x 32 cells; all tiles with the same progress
 //     I' + J' + K' (tile coordinates counted in sweep direction) are independent of each
-//     other for a 6-neighbour star and are relaxed by ONE launch pair: tile_plan_kernel lists
-//     the tiles of the hyperplane that are due (something near them changed since they were
-//     last relaxed), tile_sweep_kernel - a persistent grid of single-wavefront workgroups,
-//     as many as the device holds at once - relaxes list entries b, b + grid, ... (no cursor,
-//     no per-tile atomics: see the planner); the launches of a sweep follow each other on
+//     other for a 6-neighbour star and are relaxed by ONE launch: a grid of single-wavefront
+//     workgroups, as many as the device holds at once, whose workgroups first find the tiles
+//     of the hyperplane that are due among their own share of the candidates (something near
+//     them changed since they were last relaxed) and then relax those (no list, no cursor,
+//     no per-tile atomics: tile_candidate); the launches of a sweep follow each other on
 //     the stream;
 //   * inside a tile, lane (i', j') walks its z-column: in step d it relaxes the cell with
 //     k' = d - i' - j' (the 6-neighbour instance: the two cells 2m, 2m + 1 with
@@ -46,26 +46,43 @@ __device__ __forceinline__ tile_rsrc tile_make_rsrc(const float *base)
 }
 
 // Activity words of a tile (StartDesc::tile_flags viewed as int2): x = epoch (launch
-// number) in which the tile was last relaxed, y = epoch in which it last improved.  A tile
-// is due when one of its 27 neighbours (itself included) improved in or after the epoch it
-// was last relaxed in; relaxing it against unchanged surroundings cannot improve anything
-// (an ordering sweep relaxes every cell against its whole star).
+// number) in which the tile was last relaxed, y = the latest epoch in which one of its 27
+// neighbours (itself included) improved.  A tile is due when y >= x: something in its
+// surroundings improved in or after the epoch it was last relaxed in; relaxing it against
+// unchanged surroundings cannot improve anything (an ordering sweep relaxes every cell against
+// its whole star).  A tile that improves stamps the y words of its 27 neighbours (one store
+// instruction, a lane per neighbour), so that planning reads ONE int2 per candidate - in round
+// 2 the planner gathered 27 stamps per candidate in every one of the ~5700 launches of a solve,
+// whether or not anything had changed.
 __global__ void __launch_bounds__(256)
-init_tile_state_kernel(int2 *__restrict__ state, int ntiles, int start_tile)
+init_tile_state_kernel(int2 *__restrict__ state, int NJ, int NK, int ntiles, int si, int sj, int sk)
 {
     const int t = blockIdx.x * 256 + threadIdx.x;
     if (t >= ntiles) return;
-    state[t] = make_int2(1, (start_tile < 0 || t == start_tile) ? 1 : 0);
+    const int K = t % NK, J = (t / NK) % NJ, I = t / (NK * NJ);
+    // (si < 0: a box that arrives with values in it - every tile is due)
+    const bool near_start = si < 0 || (abs(I - si) <= 1 && abs(J - sj) <= 1 && abs(K - sk) <= 1);
+    state[t] = make_int2(1, near_start ? 1 : 0);
+}
+
+// A tile of start-state `state` improved in this launch: its 27 neighbours have to look again.
+__device__ __forceinline__ void tile_stamp_neighbours(const TileSweep &P, int2 *__restrict__ state, int I, int J, int K,
+                                                      int lane)
+{
+    if (lane < 27) {
+        const int ni = I + lane / 9 - 1, nj = J + (lane / 3) % 3 - 1, nk = K + lane % 3 - 1;
+        if ((unsigned)ni < (unsigned)P.NI && (unsigned)nj < (unsigned)P.NJ && (unsigned)nk < (unsigned)P.NK)
+            state[(ni * P.NJ + nj) * P.NK + nk].y = P.epoch;
+    }
 }
 
 hipError_t launch_init_tile_state(const DevLayout &L, const StartDesc &sd, bool from_box, hipStream_t st)
 {
     const int NI = tile_count(L.n[0], TILE_X), NJ = tile_count(L.n[1], TILE_Y), NK = tile_count(L.n[2], TILE_Z);
     const int ntiles = NI * NJ * NK;
-    const int start_tile = from_box ? -1
-        : ((sd.sa / TILE_X) * NJ + sd.sb / TILE_Y) * NK + sd.sc / TILE_Z;
     hipLaunchKernelGGL(init_tile_state_kernel, dim3((ntiles + 255) / 256), dim3(256), 0, st,
-                       reinterpret_cast<int2 *>(sd.tile_flags), ntiles, start_tile);
+                       reinterpret_cast<int2 *>(sd.tile_flags), NJ, NK, ntiles,
+                       from_box ? -1 : sd.sa / TILE_X, sd.sb / TILE_Y, sd.sc / TILE_Z);
     return hipGetLastError();
 }
 
@@ -130,72 +147,44 @@ __device__ __forceinline__ T *uni_ptr(T *p)
 }
 
 // ---------------------------------------------------------------------------
-// planning a launch: which tiles of hyperplane D are due
+// planning inside the sweep kernels: which tiles of hyperplane D are due
 // ---------------------------------------------------------------------------
-// One thread per (active start, J', K'); the tile is due when one of its 27 neighbours
-// (itself included) improved in or after the epoch it was last relaxed in.  Due tiles are
-// stamped with this epoch and appended to `list` (wave-aggregated); ctrl[0] counts them.
-// The planner also keeps the starts' work counters (relaxations, tiles): one pair of atomics
-// per wavefront and start here instead of one per tile in the sweep kernel, where 10^4
-// workgroups adding to the same few words held every tile up (measured: 22 of 60 ms of a
-// full sweep on 1024x1024x512 x 14 starts went to the per-tile counter and cursor atomics).
-__global__ void __launch_bounds__(256)
-tile_plan_kernel(TileSweep P, int2 *__restrict__ list, int *__restrict__ ctrl)
+// A launch relaxes the due tiles of ONE hyperplane D for every active start; there is no
+// separate planning kernel and no list (round 2 had both: 5.8 us of planner and a second
+// kernel boundary in front of every one of the ~5700 launches of a solve).  The grid is
+// G workgroups per active start; workgroup (start, g) owns the candidates (J', K') with linear
+// index g, g + G, g + 2 G, ... of its start - round-robin, so that a spatial cluster of due
+// tiles spreads over the workgroups - evaluates up to 64 of them at a time, one per lane (the
+// tile's two stamps, one 8-byte load), and then relaxes the due ones in turn.  A tile is due
+// when one of its 27 neighbours (itself included) improved in or after the epoch it was last
+// relaxed in (they stamp its y word when they do: tile_stamp_neighbours).
+// Tiles of the same hyperplane may improve while a workgroup is still evaluating: it then
+// either sees the new stamp (and relaxes a tile that would have been due in the next sweep
+// anyway) or does not (the stamp is >= the tile's own, so the tile is due in a later launch):
+// nothing is ever skipped for good.
+struct TileCand {
+    int tile;           // (I * NJ + J) * NK + K
+    unsigned cells;     // cells of the tile inside the grid
+    bool due;
+};
+
+__device__ __forceinline__ TileCand tile_candidate(const TileSweep &P, int2 *__restrict__ state, int c, int ncand)
 {
-    const int lane = threadIdx.x & 63;
-    const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
-    bool due = false;
-    int s = 0, tile = 0;
-    unsigned cells = 0;                     // cells of the tile inside the grid
-    if (t < (long long)P.NJ * P.NK * P.nactive) {
-        unsigned u = (unsigned)t;
-        const int Kp = u % P.NK; u /= P.NK;
-        const int Jp = u % P.NJ; u /= P.NJ;
-        const int Ip = P.D - Jp - Kp;
-        if (Ip >= 0 && Ip < P.NI) {
-            const int I = P.sx > 0 ? Ip : P.NI - 1 - Ip;
-            const int J = P.sy > 0 ? Jp : P.NJ - 1 - Jp;
-            const int K = P.sz > 0 ? Kp : P.NK - 1 - Kp;
-            s = P.active[u];
-            int2 *__restrict__ state = reinterpret_cast<int2 *>(P.state0 + (long long)s * P.state_stride);
-            tile = (I * P.NJ + J) * P.NK + K;
-            const int relaxed = state[tile].x;
-            int newest = INT_MIN;
-#pragma unroll
-            for (int n = 0; n < 27; n++) {      // (all 27 loads in flight together)
-                const int ni = min(max(I + n / 9 - 1, 0), P.NI - 1), nj = min(max(J + (n / 3) % 3 - 1, 0), P.NJ - 1),
-                          nk = min(max(K + n % 3 - 1, 0), P.NK - 1);
-                newest = max(newest, state[(ni * P.NJ + nj) * P.NK + nk].y);
-            }
-            due = newest >= relaxed;
-            if (due) state[tile].x = P.epoch;
-            cells = (unsigned)(min(TILE_X, P.L.n[0] - I * TILE_X) * min(TILE_Y, P.L.n[1] - J * TILE_Y)
-                               * min(TILE_Z, P.L.n[2] - K * TILE_Z));
-        }
-    }
-    const unsigned long long m = __ballot(due);
-    if (m == 0ull) return;
-    int base = 0;
-    if (lane == __builtin_ctzll(m)) base = atomicAdd(&ctrl[0], __popcll(m));
-    base = __shfl(base, __builtin_ctzll(m));
-    if (due) list[base + __popcll(m & ((1ull << lane) - 1ull))] = make_int2(s, tile);
-    // work counters: the due lanes of one start at a time (a wavefront rarely spans two)
-    unsigned long long rest = m;
-    while (rest) {
-        const int first = __builtin_ctzll(rest);
-        const int s0 = __shfl(s, first);
-        const bool mine = due && s == s0;
-        const unsigned long long mm = __ballot(mine);
-        unsigned sum = mine ? cells : 0u;
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
-        if (lane == first) {
-            unsigned long long *const work = P.work0 + 3 * s0;
-            atomicAdd(work, (unsigned long long)sum * (unsigned long long)P.nent);
-            atomicAdd(work + 2, (unsigned long long)__popcll(mm));
-        }
-        rest &= ~mm;
-    }
+    TileCand r{0, 0u, false};
+    if (c >= ncand) return r;
+    const int Kp = c % P.NK, Jp = c / P.NK;
+    const int Ip = P.D - Jp - Kp;
+    if (Ip < 0 || Ip >= P.NI) return r;
+    const int I = P.sx > 0 ? Ip : P.NI - 1 - Ip;
+    const int J = P.sy > 0 ? Jp : P.NJ - 1 - Jp;
+    const int K = P.sz > 0 ? Kp : P.NK - 1 - Kp;
+    r.tile = (I * P.NJ + J) * P.NK + K;
+    const int2 stamps = state[r.tile];
+    r.due = stamps.y >= stamps.x;
+    if (r.due) state[r.tile].x = P.epoch;
+    r.cells = (unsigned)(min(TILE_X, P.L.n[0] - I * TILE_X) * min(TILE_Y, P.L.n[1] - J * TILE_Y)
+                         * min(TILE_Z, P.L.n[2] - K * TILE_Z));
+    return r;
 }
 
 // -DTTSWEEP_TILE_PROFILE: cycle stamps per phase of a tile, summed over all tiles (tuning aid;
@@ -227,12 +216,22 @@ void tile_prof_dump()
 // ---------------------------------------------------------------------------
 // relaxing the due tiles: a persistent grid of single-wavefront workgroups
 // ---------------------------------------------------------------------------
-// Read-only tables written before the launch (the start descriptors, the list of due tiles)
-// are read through the scalar cache: uniform addresses in the constant address space become
-// s_load instructions, a few hundred cycles instead of a vector-memory round trip per tile.
-struct TileItem { int s, tile; };        // (an int2 as the planner writes it)
+// Read-only tables written before the launch (the start descriptors) are read through the
+// scalar cache: uniform addresses in the constant address space become s_load instructions, a
+// few hundred cycles instead of a vector-memory round trip per tile.
 typedef const __attribute__((address_space(4))) StartDesc *const_start_ptr;
-typedef const __attribute__((address_space(4))) TileItem *const_item_ptr;
+
+// The work counters of a start (relaxations, tiles): one pair of atomics per workgroup and
+// launch, after its last tile (10^4 workgroups adding per TILE to the same few words held every
+// tile up: 22 of 60 ms of a full sweep on 1024x1024x512 x 14 starts in round 2).
+__device__ __forceinline__ void tile_work_add(const TileSweep &P, int s, unsigned long long cells, unsigned tiles, int lane)
+{
+    if (lane == 0 && tiles) {
+        unsigned long long *const work = P.work0 + 3 * s;
+        atomicAdd(work, cells * (unsigned long long)P.nent);
+        atomicAdd(work + 2, (unsigned long long)tiles);
+    }
+}
 
 // The 6-neighbour star with halo 1, entries in the pull star's order (sorted by offset):
 // image index deltas and everything derived from them are compile-time constants.
@@ -245,12 +244,11 @@ typedef float tile_f2 __attribute__((ext_vector_type(2)));
 // of its own, tile_six_kernel.)
 template <int NE, bool EXACT>
 __global__ void __launch_bounds__(64)
-tile_sweep_kernel(TileSweep P, const int2 *__restrict__ list, const int *__restrict__ ctrl)
+tile_sweep_kernel(TileSweep P)
 {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int lane = threadIdx.x;
     const DevLayout &L = P.L;
-    const int count = ctrl[0];
 
     const int R = P.R;
     const int SY = TILE_Y + 2 * R;
@@ -276,22 +274,28 @@ tile_sweep_kernel(TileSweep P, const int2 *__restrict__ list, const int *__restr
     // (the same for every tile: computed once, kept for the first iterations' worth)
     const int dat = P.sz > 0 ? 1 : -1;
 
-    // Workgroup b relaxes entries b, b + gridDim.x, ...: no cursor.  The tiles of a launch cost
-    // about the same, and an atomic per tile on one word - whose answer the wave's vmcnt(0)
-    // below has to wait for, behind every other workgroup's - cost more than the balance was
-    // worth (with the per-tile work counters: 22 of 60 ms of a full sweep).
 #ifdef TTSWEEP_TILE_PROFILE
     unsigned long long prof_acc[5] = {};
 #endif
     PROF_STAMP(t_begin);
-    // (everything that selects the tile is kept in scalar registers: the list entry and the
-    // start descriptor then come through the scalar cache and the buffer descriptors need no
-    // waterfall loop)
-    const int nwg = uni((int)gridDim.x), ntodo = uni(count);
-    int flagged = -1;           // start whose "improved" bit this workgroup has set in this launch
-    for (int next = uni((int)blockIdx.x); next < ntodo; next = uni(next + nwg)) {
-        const const_item_ptr ip_ = (const_item_ptr)(list + next);
-        const int s = ip_->s, tile = ip_->tile;
+    // (everything that selects the tile is kept in scalar registers: the start descriptor then
+    // comes through the scalar cache and the buffer descriptors need no waterfall loop)
+    const int G = uni(P.groups), g = uni((int)blockIdx.x % P.groups);
+    const int s = uni(P.active[blockIdx.x / P.groups]);
+    int2 *const state_s = reinterpret_cast<int2 *>(P.state0 + (long long)s * P.state_stride);
+    const int ncand = P.NJ * P.NK;
+    unsigned long long work_cells = 0;
+    unsigned work_tiles = 0;
+    bool flagged = false;       // this workgroup has set the start's "improved" bit in this launch
+    for (int c0 = g; c0 < ncand; c0 += 64 * G) {
+      const TileCand pick = tile_candidate(P, state_s, c0 + lane * G, ncand);
+      unsigned long long due_lanes = __ballot(pick.due);
+      while (due_lanes) {
+        const int src = __builtin_ctzll(due_lanes);
+        due_lanes &= due_lanes - 1;
+        const int tile = __builtin_amdgcn_readlane(pick.tile, src);
+        work_cells += (unsigned)__builtin_amdgcn_readlane((int)pick.cells, src);
+        work_tiles++;
         PROF_STAMP(t_top);
 
         const const_start_ptr sdp = (const_start_ptr)(P.starts + s);
@@ -437,12 +441,12 @@ tile_sweep_kernel(TileSweep P, const int2 *__restrict__ list, const int *__restr
                     tf[tile_face_index(L, FZ, K + 1, 0, l, pa, pb)] = timg[row0 + TILE_Z - FZ + l];
                 }
             }
-            if (lane == 0) state[tile].y = P.epoch;
-            // (once per workgroup and start: the list is sorted by start, and an atomic per
-            // improved tile on the starts' few words holds every tile up - see the planner)
-            if (s != flagged) {
+            tile_stamp_neighbours(P, state, I, J, K, lane);
+            // (once per workgroup: an atomic per improved tile on the starts' few words holds
+            // every tile up - see tile_work_add)
+            if (!flagged) {
                 if (lane == 0) atomicOr(&P.changed[s], CHANGED_IMPROVED);
-                flagged = s;
+                flagged = true;
             }
         }
         // (the image is overwritten by the next tile's loads: every read of it has been
@@ -458,7 +462,9 @@ tile_sweep_kernel(TileSweep P, const int2 *__restrict__ list, const int *__restr
             prof_acc[4] += 1ull;
         }
 #endif
+      }
     }
+    tile_work_add(P, s, work_cells, work_tiles, lane);
 #ifdef TTSWEEP_TILE_PROFILE
     if (lane == 0 && prof_acc[4]) {
         for (int i = 0; i < 5; i++) atomicAdd(&g_tile_prof[i], prof_acc[i]);
@@ -578,12 +584,11 @@ __device__ __forceinline__ bool sixc_sweep(float *img, int row, int ij, int klo,
 }
 
 __global__ void __launch_bounds__(64)
-tile_six_kernel(TileSweep P, const int2 *__restrict__ list, const int *__restrict__ ctrl)
+tile_six_kernel(TileSweep P)
 {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int lane = threadIdx.x;
     const DevLayout &L = P.L;
-    const int count = ctrl[0];
     float *const img = lds + SIXC_PAD;              // v rows; T rows SIXC_T behind; halo tables behind them
 
     const int ip = lane >> 3, jp = lane & 7;
@@ -596,16 +601,25 @@ tile_six_kernel(TileSweep P, const int2 *__restrict__ list, const int *__restric
     unsigned long long prof_acc[5] = {};
 #endif
     PROF_STAMP(t_begin);
-    const int nwg = uni((int)gridDim.x), ntodo = uni(count);
-    int flagged = -1;
-    for (int next = uni((int)blockIdx.x); next < ntodo; next = uni(next + nwg)) {
-        const const_item_ptr ip_ = (const_item_ptr)(list + next);
-        const int s = ip_->s, tile = ip_->tile;
+    // (the start's volume and activity words from the launch arguments: no descriptor load)
+    const int G = uni(P.groups), g = uni((int)blockIdx.x % P.groups);
+    const int s = uni(P.active[blockIdx.x / P.groups]);
+    float *const T = uni_ptr(P.T0 + (long long)s * L.cells);
+    int2 *const state = uni_ptr(reinterpret_cast<int2 *>(P.state0 + (long long)s * P.state_stride));
+    const int ncand = P.NJ * P.NK;
+    unsigned long long work_cells = 0;
+    unsigned work_tiles = 0;
+    bool flagged = false;
+    for (int c0 = g; c0 < ncand; c0 += 64 * G) {
+      const TileCand pick = tile_candidate(P, state, c0 + lane * G, ncand);
+      unsigned long long due_lanes = __ballot(pick.due);
+      while (due_lanes) {
+        const int src = __builtin_ctzll(due_lanes);
+        due_lanes &= due_lanes - 1;
+        const int tile = __builtin_amdgcn_readlane(pick.tile, src);
+        work_cells += (unsigned)__builtin_amdgcn_readlane((int)pick.cells, src);
+        work_tiles++;
         PROF_STAMP(t_top);
-        // (the start's volume and activity words from the launch arguments: no descriptor load
-        // between the list entry and the first staging instruction)
-        float *const T = P.T0 + (long long)s * L.cells;
-        int2 *const state = reinterpret_cast<int2 *>(P.state0 + (long long)s * P.state_stride);
         const int K = tile % P.NK, J = (tile / P.NK) % P.NJ, I = tile / (P.NK * P.NJ);
 
         // ---- stage: rows (x - 1 .. x + 8, y - 1 .. y + 8) but the two corner rows at the ends,
@@ -673,10 +687,10 @@ tile_six_kernel(TileSweep P, const int2 *__restrict__ list, const int *__restric
             const int pa = I * TILE_X + 1 + ci, pb = J * TILE_Y + 1 + cj;
             tface[tile_face_index(L, 1, K, 1, 0, pa, pb)] = img[SIXC_T + row * TILE_Z];
             tface[tile_face_index(L, 1, K + 1, 0, 0, pa, pb)] = img[SIXC_T + row * TILE_Z + TILE_Z - 1];
-            if (lane == 0) state[tile].y = P.epoch;
-            if (s != flagged) {
+            tile_stamp_neighbours(P, state, I, J, K, lane);
+            if (!flagged) {
                 if (lane == 0) atomicOr(&P.changed[s], CHANGED_IMPROVED);
-                flagged = s;
+                flagged = true;
             }
         }
 #ifdef TTSWEEP_TILE_PROFILE
@@ -689,7 +703,9 @@ tile_six_kernel(TileSweep P, const int2 *__restrict__ list, const int *__restric
             prof_acc[4] += 1ull;
         }
 #endif
+      }
     }
+    tile_work_add(P, s, work_cells, work_tiles, lane);
 #ifdef TTSWEEP_TILE_PROFILE
     if (lane == 0 && prof_acc[4]) {
         for (int i = 0; i < 5; i++) atomicAdd(&g_tile_prof[i], prof_acc[i]);
@@ -704,7 +720,7 @@ size_t tile_lds_bytes(int R)
     return (size_t)2 * nslots * 16;
 }
 
-typedef void (*tile_sweep_fn)(TileSweep, const int2 *, const int *);
+typedef void (*tile_sweep_fn)(TileSweep);
 
 // The instance that relaxes this star (see tile_sweep_kernel's template parameters).
 static tile_sweep_fn tile_instance(const TileSweep &P)
@@ -713,7 +729,9 @@ static tile_sweep_fn tile_instance(const TileSweep &P)
     for (int e = 0; e < P.nent; e++) exact |= P.ent[e].flags != (PULL_FWD | PULL_REV);
     // the plain 6-neighbour star (entries in the pull star's sorted order) has its own instance
     static const int six[6][3] = {{-1, 0, 0}, {0, -1, 0}, {0, 0, -1}, {0, 0, 1}, {0, 1, 0}, {1, 0, 0}};
-    bool is_six = P.nent == 6 && P.R == 1 && !exact;
+    // (its face offsets are 32-bit byte offsets from one descriptor: a start's faces must stay
+    // below 4 GiB - about a 2600^3 grid -, beyond that the general kernel's 64-bit indices serve)
+    bool is_six = P.nent == 6 && P.R == 1 && !exact && tile_face_cells(P.L, 1) * 4 < 0x100000000LL;
     for (int e = 0; e < 6 && is_six; e++)
         is_six = P.ent[e].da == six[e][0] && P.ent[e].db == six[e][1] && P.ent[e].dc == six[e][2];
     if (is_six) return tile_six_kernel;
@@ -751,16 +769,13 @@ hipError_t tile_sweep_wgs_per_cu(const TileSweep &P, int *wgs)
     return hipSuccess;
 }
 
-hipError_t launch_tile_sweep(const TileSweep &P, int2 *list, int *ctrl, int nblocks, hipStream_t st)
+hipError_t launch_tile_sweep(const TileSweep &P, hipStream_t st)
 {
     if (P.nactive <= 0) return hipSuccess;
-    if (!tile_sweep_ok(P) || nblocks < 1) return hipErrorInvalidValue;
-    const long long cand = (long long)P.NJ * P.NK * P.nactive;
-    if (cand > 0x7fffffffLL) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(tile_plan_kernel, dim3((unsigned)((cand + 255) / 256)), dim3(256), 0, st, P, list, ctrl);
-    nblocks = (int)std::min<long long>(nblocks, cand);
-    hipLaunchKernelGGL(tile_instance(P), dim3((unsigned)nblocks), dim3(64), tile_instance_lds(P), st, P,
-                       (const int2 *)list, (const int *)ctrl);
+    if (!tile_sweep_ok(P) || P.groups < 1) return hipErrorInvalidValue;
+    const long long nblocks = (long long)P.groups * P.nactive;
+    if (nblocks > 0x7fffffffLL) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(tile_instance(P), dim3((unsigned)nblocks), dim3(64), tile_instance_lds(P), st, P);
     return hipGetLastError();
 }
 

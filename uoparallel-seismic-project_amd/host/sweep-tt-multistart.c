@@ -225,6 +225,15 @@ int main(int argc, char *argv[])
 } /* main */
 
 
+/* Runs before main(): the HIP runtime starts to initialise on a thread of the library while
+ * main() reads its three files and prepares the boxes (:77-147), instead of inside the first
+ * sweepXYZ call.  Part of the sweepXYZ binding, not of main(); never needed for correctness. */
+__attribute__((constructor)) static void sweep_warmup(void)
+{
+    const char *dev = getenv("TTSWEEP_DEVICE");
+    ttsweep_warmup(dev ? atoi(dev) : 0);
+}
+
 /* Drop-in for the reference's sweepXYZ (:198-256).  The first call of a pass
  * (s == 0) hands ALL starts to the library in one batched solve (they share
  * the velocity volume on the device); the calls for s > 0 only report what

@@ -6,7 +6,9 @@ loop has no cross-iteration dependence; mpi/backup.c:351-363 already runs one
 start per rank), so starts are the unit of distribution: one process per GPU,
 no communication while sweeping, and one final gather of the per-start boxes to
 rank 0 - the step the reference left as a TODO (mpi/backup.c:381-386).  With
-backend "nccl" (RCCL on ROCm) the gather moves device buffers over xGMI.
+backend "nccl" (RCCL on ROCm) the gather moves device buffers over xGMI, every box
+straight into its slot of the result; a result set that does not fit the root's GPU
+(1024x1024x512 x 111 starts) is gathered into host memory instead (plan_gather).
 
 The solver is injected (`solve_fn`) so the same sharding/gather code runs under
 the CPU test tier with backend "gloo".
@@ -54,12 +56,68 @@ def shard_sizes(nstart: int, world_size: int) -> List[int]:
     return [len(range(r, nstart, world_size)) for r in range(world_size)]
 
 
-def gather_boxes(local, nstart: int, dist=None, dst: int = 0, shards=None):
-    """Gather the per-rank stacks of boxes [n_local, nx, ny, nz] on rank `dst` and
-    return them ordered by global start index ([nstart, nx, ny, nz]); other ranks
-    return None.  Ranks may hold different numbers of starts; stacks are padded to
-    the largest shard for the collective.  `shards`: the assignment in use (all_shards);
-    round-robin when omitted."""
+# What share of the root's free device memory the gathered result set may take before the
+# gather goes to host memory instead (the root also holds its own shard, the padded volumes
+# of the solver and the velocity).
+DEVICE_GATHER_FRACTION = 0.5
+
+
+def plan_gather(nstart: int, box_bytes: int, free_device_bytes: int | None,
+                fraction: float = DEVICE_GATHER_FRACTION) -> dict:
+    """Where the final gather of `nstart` boxes of `box_bytes` each goes:
+    "device" - rank `dst` receives every remote box straight into its slot of one device
+    array (RCCL send / recv over xGMI) - while the whole set fits `fraction` of the root's free
+    device memory; "host" beyond that (1024x1024x512 x 111 starts = 238 GB do not fit one
+    288 GB GPU next to the solver's own volumes): every rank copies its boxes from its GPU into
+    ONE array in host memory.  `free_device_bytes` None (no device: CPU rehearsal) -> "host"."""
+    total = int(nstart) * int(box_bytes)
+    if free_device_bytes is None:
+        return {"path": "host", "bytes": total, "why": "no device memory to gather into"}
+    budget = int(fraction * free_device_bytes)
+    if total <= budget:
+        return {"path": "device", "bytes": total,
+                "why": f"{total / 1e9:.2f} GB <= {fraction:.2f} x {free_device_bytes / 1e9:.1f} GB free on the root"}
+    return {"path": "host", "bytes": total,
+            "why": f"{total / 1e9:.2f} GB > {fraction:.2f} x {free_device_bytes / 1e9:.1f} GB free on the root"}
+
+
+def _same_host(dist) -> bool:
+    """Do all ranks run on one machine (one node: the case the north star names)?"""
+    import socket
+    names = [None] * dist.get_world_size()
+    dist.all_gather_object(names, socket.gethostname())
+    return len(set(names)) == 1
+
+
+_cpu_group = None
+
+
+def _host_group(dist):
+    """A process group that can move CPU tensors: the default one unless it is RCCL-only."""
+    global _cpu_group
+    if "gloo" in str(dist.get_backend()):
+        return None                                 # (the default group does)
+    if _cpu_group is None:
+        _cpu_group = dist.new_group(backend="gloo")
+    return _cpu_group
+
+
+def gather_boxes(local, nstart: int, dist=None, dst: int = 0, shards=None, path: str = "device",
+                 shm_dir: str = "/dev/shm", tag: str = "ttsweep"):
+    """Gather the per-rank stacks of boxes [n_local, nx, ny, nz] on rank `dst`, ordered by
+    global start index ([nstart, nx, ny, nz]); other ranks return None.  Ranks may hold
+    different numbers of starts (`shards`: the assignment in use, all_shards; round-robin when
+    omitted).  This is the step the reference left as a TODO (mpi/backup.c:381-386).
+
+    path "device": grouped point-to-point transfers (batch_isend_irecv: ncclSend / ncclRecv in
+        one group under backend "nccl", i.e. RCCL over xGMI; isend / irecv under gloo) of every
+        box STRAIGHT INTO its slot of the result - no padding to the largest shard, no staging
+        stacks, no reorder copy: the root holds the result set once, next to its own shard.
+    path "host": the result lives in host memory.  All ranks on one machine: rank `dst` creates
+        one array in shared memory (a file under `shm_dir`), every rank maps it and copies its
+        boxes from its GPU straight into their slots (D2H over PCIe, all GPUs at once, no
+        inter-process copy); ranks on different machines: the boxes travel as CPU tensors over
+        a gloo group.  The returned tensor is a CPU tensor (shared mapping or plain)."""
     import torch
 
     if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
@@ -67,26 +125,72 @@ def gather_boxes(local, nstart: int, dist=None, dst: int = 0, shards=None):
     world, rank = dist.get_world_size(), dist.get_rank()
     if shards is None:
         shards = all_shards(nstart, world)
-    nmax = max(len(sh) for sh in shards)
     box_shape = tuple(local.shape[1:])
-    send = local
-    if local.shape[0] < nmax:
-        send = torch.zeros((nmax,) + box_shape, dtype=local.dtype, device=local.device)
-        send[: local.shape[0]] = local
-    send = send.contiguous()
-    if rank == dst:
-        recv = [torch.empty_like(send) for _ in range(world)]
-        dist.gather(send, gather_list=recv, dst=dst)
-        out = torch.empty((nstart,) + box_shape, dtype=local.dtype, device=local.device)
-        for r in range(world):
-            for n, s in enumerate(shards[r]):
-                out[s] = recv[r][n]
+    mine = shards[rank]
+    if local.shape[0] != len(mine):
+        raise ValueError(f"rank {rank} holds {local.shape[0]} boxes, its shard has {len(mine)}")
+    local = local.contiguous()
+
+    if path == "device":
+        out = None
+        ops = []
+        if rank == dst:
+            out = torch.empty((nstart,) + box_shape, dtype=local.dtype, device=local.device)
+            for n, s in enumerate(mine):
+                out[s].copy_(local[n])
+            for r in range(world):
+                if r != dst:
+                    ops += [dist.P2POp(dist.irecv, out[s], r) for s in shards[r]]
+        else:
+            ops = [dist.P2POp(dist.isend, local[n], dst) for n in range(len(mine))]
+        if ops:
+            for req in dist.batch_isend_irecv(ops):
+                req.wait()
         return out
-    dist.gather(send, gather_list=None, dst=dst)
-    return None
+
+    if path != "host":
+        raise ValueError(f"unknown gather path {path!r}")
+    numel = int(np.prod(box_shape)) if box_shape else 1
+    if _same_host(dist):
+        import os
+        name = [None]
+        if rank == dst:
+            name[0] = os.path.join(shm_dir, f"{tag}_{os.getpid()}_{nstart}x{numel}.f32")
+            with open(name[0], "wb") as f:
+                f.truncate(max(nstart * numel, 1) * 4)
+        dist.broadcast_object_list(name, src=dst)
+        out = torch.from_file(name[0], shared=True, size=max(nstart * numel, 1), dtype=torch.float32)
+        out = out[: nstart * numel].view((nstart,) + box_shape)
+        for n, s in enumerate(mine):
+            out[s].copy_(local[n])                  # device -> the shared host array (or host -> host)
+        if local.is_cuda:
+            torch.cuda.synchronize(local.device)
+        dist.barrier()                              # every slot is written
+        if rank == dst:
+            os.unlink(name[0])                      # (the mapping keeps the memory until it is dropped)
+            return out
+        return None
+    group = _host_group(dist)
+    out = None
+    ops = []
+    if rank == dst:
+        out = torch.empty((nstart,) + box_shape, dtype=local.dtype)
+        for n, s in enumerate(mine):
+            out[s].copy_(local[n])
+        for r in range(world):
+            if r != dst:
+                ops += [dist.P2POp(dist.irecv, out[s], r, group) for s in shards[r]]
+    else:
+        host = local.cpu()
+        ops = [dist.P2POp(dist.isend, host[n], dst, group) for n in range(len(mine))]
+    if ops:
+        for req in dist.batch_isend_irecv(ops):
+            req.wait()
+    return out
 
 
-def solve_sharded(starts: Sequence, solve_fn: Callable, dist=None, dst: int = 0, shape=None):
+def solve_sharded(starts: Sequence, solve_fn: Callable, dist=None, dst: int = 0, shape=None,
+                  path: str = "device"):
     """Solve this rank's shard with `solve_fn(list_of_starts) -> tensor[n_local,...]`
     and gather all boxes on rank `dst`.  Returns (all_boxes_or_None, local_boxes).  With
     the grid `shape` the shards are balanced by estimated cost, else dealt round-robin."""
@@ -97,7 +201,7 @@ def solve_sharded(starts: Sequence, solve_fn: Callable, dist=None, dst: int = 0,
         world, rank = dist.get_world_size(), dist.get_rank()
     shards = all_shards(len(starts), world, starts if shape is not None else None, shape)
     local = solve_fn(starts[shards[rank]])
-    return gather_boxes(local, len(starts), dist, dst, shards=shards), local
+    return gather_boxes(local, len(starts), dist, dst, shards=shards, path=path), local
 
 
 # --------------------------------------------------------------------------
