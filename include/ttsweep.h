@@ -132,7 +132,11 @@ int ttsweep_set_option(ttsweep_ctx *ctx, int key, long long value);
 /* Velocity volume (the global `vbox.box.flat`, :65), host or device memory,
  * FLOATBOX layout.  The library keeps its own device copy.  Every value must be finite
  * and >= 0 (zero is accepted as the reference accepts it; a negative velocity, for which
- * the reference's loop :151-170 need not terminate, Inf and NaN are refused: < 0). */
+ * the reference's loop :151-170 need not terminate, Inf and NaN are refused: < 0), and a
+ * positive value must be at least 2^-124 / (smallest fs[].d of the star) - about 4.7e-39
+ * for the reference's delta of 10 -: below that a delay d * (v[c] + v[o]) can be a denormal
+ * number, where the reference's "/ 2.0" of the rounded product (:216) and the kernels'
+ * multiplication by d / 2 no longer agree in the last bit; such volumes are refused too. */
 int ttsweep_set_velocity(ttsweep_ctx *ctx, const float *v_host);
 int ttsweep_set_velocity_device(ttsweep_ctx *ctx, const float *v_dev);
 

@@ -752,28 +752,41 @@ def _boxes(shape, starts):
 
 
 @pytest.mark.parametrize("kernel", KERNELS + [pytest.param(3, id="tile")])
-def test_denormal_delays_vs_oracle(P, oracle, kernel):
-    """Velocities of 1e-42 .. 1e-30: velocities, delays and travel times partly in the denormal
-    range (< 1.18e-38).  The x86 reference keeps denormals; the kernels are built with
-    -fno-honor-nans -mno-amdgpu-ieee and use v_pk_mul_f32 / v_pk_add_f32 / v_min3_f32: their
-    denormal handling must match bit for bit."""
+def test_tiny_velocities(P, oracle, kernel):
+    """The small end of the velocity range.  The reference halves the ROUNDED product
+    d * (v[c] + v[o]) (serial_new/sweep-tt-multistart.c:216), the kernels multiply by d / 2; the
+    two agree bit for bit while that product is a normal number - a first version of this test
+    with velocities of 1e-42 found 1-ulp differences in the denormal range, on every kernel.
+    The boundary therefore refuses velocities whose delays could be denormal (0 < v < 2^-124 /
+    d_min), and everything it accepts - here 2e-39 .. 1e-30, delays and travel times down to
+    the smallest normal numbers - matches the oracle bit for bit (the kernels are built with
+    -fno-honor-nans -mno-amdgpu-ieee and use v_pk_mul_f32 / v_pk_add_f32 / v_min3_f32)."""
     rng = np.random.default_rng(77)
     shape = (26, 40, 21)
-    v = (10.0 ** rng.uniform(-42.0, -30.0, size=shape)).astype(np.float32)
-    v[3:9, 5:30, 2:15] = np.float32(2e-41)          # a block of denormal velocities (one start inside it)
-    assert (v > 0).all() and (v < np.float32(1.2e-38)).any()
     offs = P.inputs.read_triples(P.inputs.star_path("six" if kernel == 3 else "5"))
+    fs = P.inputs.make_fs(offs)
+    tiny = float(2.0 ** -124 / 10.0)                # d_min = delta * 1 = 10 for both stars
+    v = (10.0 ** rng.uniform(np.log10(tiny) + 0.01, -30.0, size=shape)).astype(np.float32)
+    v[3:9, 5:30, 2:15] = np.float32(tiny * 1.0001)  # a block at the smallest accepted velocity (one start inside it)
     starts = np.array([[13, 20, 20], [0, 0, 0], [5, 10, 7]], dtype=np.int32)
     ofs = oracle.make_star(offs)
-    tts, rc, st = gpu_converge(P, v, P.inputs.make_fs(offs), starts, kernel=kernel)
+    tts, rc, st = gpu_converge(P, v, fs, starts, kernel=kernel)
     assert rc == 1 and st["kernel_variant"] == (2 if kernel > 20 else kernel)
-    denormal_times = 0
+    smallest = np.inf
     for start, tt in zip(starts, tts):
         want, _, _ = oracle.converge(v, ofs, start, order=1)
         assert np.isfinite(want).all()
-        denormal_times += int((want[want > 0] < np.float32(1.2e-38)).sum())
+        smallest = min(smallest, float(want[want > 0].min()))
         assert_bit_equal(tt, want, f"kernel {kernel}, start {start}")
-    assert denormal_times > 1000        # (the start inside the block: thousands of denormal travel times)
+    assert smallest < 1e-37                         # (travel times a few binades above the denormal range)
+    with P.TravelTimeSolver(shape, fs) as sol:      # below the limit: refused, loudly
+        if kernel != 3:
+            sol.set_option(P.OPT_KERNEL, 2 if kernel > 20 else kernel)
+        for bad in (tiny * 0.99, 1e-42, 1.5e-45):
+            w = v.copy()
+            w[1, 2, 3] = np.float32(bad)
+            with pytest.raises(P.TTSweepError, match="denormal"):
+                sol.set_velocity(w)
 
 
 @pytest.mark.parametrize("kernel", KERNELS + [pytest.param(3, id="tile")])

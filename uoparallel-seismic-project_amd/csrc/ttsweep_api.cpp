@@ -185,6 +185,7 @@ void ttsweep_destroy(ttsweep_ctx *ctx)
     (void)hipFree(ctx->d_unitq);
     (void)hipFree(ctx->d_unitq_ctrl);
     (void)hipFree(ctx->d_work);
+    (void)hipFree(ctx->d_tile_wgwork);
     (void)hipFree(ctx->d_vface);
     (void)hipFree(ctx->d_tface);
     if (ctx->h_work) (void)hipHostFree(ctx->h_work);
@@ -287,11 +288,26 @@ int ttsweep_set_velocity_device(ttsweep_ctx *ctx, const float *v_dev)
     // every cell must be a finite number >= 0: delays are then >= 0, the relaxation has a least
     // fixed point and no NaN can arise.  Zero is accepted, as the
     // reference accepts it (zero delays: serial_new/sweep-tt-multistart.c:216 has no test);
-    // a negative velocity would make the reference loop forever and is refused here.
+    // a negative velocity would make the reference loop forever and is refused here.  So are
+    // positive velocities so small that a delay could be a denormal number: the reference
+    // halves the ROUNDED product d * (v[c] + v[o]) (:216), the kernels multiply by d / 2, and
+    // the two differ in the last bit once the product is denormal (found by the test that now
+    // pins this rule: tests/test_gpu_parity.py::test_tiny_velocities).  With the smallest
+    // offset length d_min every product is >= 2^-124 when v >= 2^-124 / d_min (a factor two above
+    // the smallest product that halves exactly).
     unsigned long long *d_bad = ctx->d_scratch, h_bad = 0;
     const long long n = (long long)ctx->nx * ctx->ny * ctx->nz;
     HIPCHK(hipMemsetAsync(d_bad, 0, sizeof(unsigned long long), ctx->stream));
-    HIPCHK(launch_count_bad_velocity(v_dev, n, d_bad, ctx->stream));
+    float tiny = 0.0f;
+    {
+        float dmin = 0.0f;
+        for (int l = ctx->starstart; l < ctx->starstop; l++) {
+            const float d = ctx->fs_copy[l].d;
+            if (d > 0.0f && (dmin == 0.0f || d < dmin)) dmin = d;
+        }
+        if (dmin > 0.0f) tiny = (float)std::min(std::ldexp(1.0, -124) / (double)dmin, 1.0e30);
+    }
+    HIPCHK(launch_count_bad_velocity(v_dev, n, tiny, d_bad, ctx->stream));
     HIPCHK(hipMemcpyAsync(&h_bad, d_bad, sizeof h_bad, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(launch_pack(ctx->L, v_dev, ctx->d_v, 0.0f, ctx->stream));
     if (ctx->kernel == TTSWEEP_KERNEL_TILE) {
@@ -302,7 +318,9 @@ int ttsweep_set_velocity_device(ttsweep_ctx *ctx, const float *v_dev)
     HIPCHK(hipStreamSynchronize(ctx->stream));
     if (h_bad) {
         ctx->have_v = false;
-        return set_error("velocity volume holds %llu cells that are negative or not finite", h_bad);
+        return set_error("velocity volume holds %llu cells that are negative, not finite, or positive but below "
+                         "%.3g (delays would be denormal numbers, where bit parity with the reference ends)",
+                         h_bad, (double)tiny);
     }
     ctx->have_v = true;
     if (ctx->pre && ttsweep_set_velocity_device(ctx->pre, v_dev) < 0) return -1;

@@ -102,6 +102,8 @@ struct ttsweep_ctx {
     int tile_epoch = 1;
     int tile_blocks = 0;                    // workgroups of the sweep kernel the device holds at once
     ttsweep::TileSweep tile_sweep{};        // launch arguments of the solve in progress
+    unsigned long long *d_tile_wgwork = nullptr;    // private work sums of the sweep kernel's workgroups
+    size_t tile_wgwork_cap = 0;
     int *d_tile_flags = nullptr;            // capacity_starts x activity words (flag_words)
     unsigned long long *d_work = nullptr;   // capacity_starts
     unsigned long long *h_work = nullptr;   // pinned

@@ -61,9 +61,11 @@ struct StartDesc {
     // that have at least one dead edge: the STRIP kernel does not store into
     // them, the exact wave-per-cell kernel owns them.  Empty if lo > hi.
     int box_lo[3], box_hi[3];
-    // STRIP activity tracking, per unit (see plan_pass_kernel): tile_flags[parity][unit]
-    // says where the unit improved in the pass with that parity; then one word per unit
-    // of held-back plane bits (pend[]), then the number of source units.
+    // STRIP activity tracking (see plan_pass_kernel, push_improved): two blocks of patch flags
+    // (plane, lane tile, strip) the initialisation uses - the second one says which patches
+    // are sources -, then one word per unit of staged-plane bits it has to relax (pend[]: pushed
+    // by whoever improves a plane, kept while the gate holds the unit back), then the number of
+    // source patches.
     int *tile_flags;
     unsigned long long *work;   // cells actually relaxed for this start (sum over passes)
 };
@@ -178,8 +180,8 @@ struct TileEntry {
 };
 
 // Arguments of one launch of tile_sweep_kernel: the tiles of hyperplane D of a sweep with
-// ordering (sx, sy, sz), for every active start.  The grid is `groups` single-wavefront
-// workgroups per active start (workgroup b: start active[b / groups], group b % groups).
+// ordering (sx, sy, sz), for every active start.  The grid is `nblocks` single-wavefront
+// workgroups; the candidates (active start, J', K') are dealt round-robin over them.
 struct TileSweep {
     DevLayout L;
     const float *v;
@@ -187,7 +189,9 @@ struct TileSweep {
     const int *active;      // indices of the active starts
     int *changed;           // "changed" words of this sweep, per start
     int nactive;
-    int groups;             // workgroups per active start
+    int nblocks;            // workgroups of the launch
+    int nstart;             // starts of the solve (slots per workgroup in wgwork)
+    unsigned long long *wgwork;     // [nblocks][nstart][2]: private work sums of the workgroups (relaxations, tiles)
     int NI, NJ, NK;         // tiles along a, b, c
     int R;                  // max |da|, |db| (halo of the staged image along a and b)
     int sx, sy, sz;         // sweep ordering, +1 / -1 per axis

@@ -42,7 +42,7 @@ static int launch_pass_strip(ttsweep_ctx *ctx, int nactive, int nstart, int *d_c
     const StripPlan &plan = ctx->plans[ctx->np - 1];
     HIPCHK(launch_plan_pass(ctx->L, ctx->d_starts, ctx->d_worklist, ctx->worklist_len, d_changed,
                             ctx->d_unitq, (int)ctx->unitq_cap, ctx->nlists, ctx->d_unitq_ctrl,
-                            plan, ctx->pass_index & 1, gate_r2(ctx), ctx->stream));
+                            plan, gate_r2(ctx), ctx->stream));
     UnitPassTail tail;
     tail.active = ctx->d_active;
     tail.nactive = nactive;
@@ -54,7 +54,7 @@ static int launch_pass_strip(ttsweep_ctx *ctx, int nactive, int nstart, int *d_c
     tail.changed_next = d_changed_next;
     HIPCHK(launch_sweep_units(ctx->L, ctx->d_v, ctx->d_starts, ctx->d_unitq, (int)ctx->unitq_cap,
                               ctx->nlists, ctx->d_unitq_ctrl, ctx->unitq_blocks, d_changed,
-                              ctx->d_strip_items[ctx->np - 1], plan, ctx->pass_index & 1, tail, ctx->stream));
+                              ctx->d_strip_items[ctx->np - 1], plan, tail, ctx->stream));
     return 0;
 }
 
@@ -81,7 +81,7 @@ static int prepare_tile_sweep(ttsweep_ctx *ctx)
     P.tface = ctx->d_tface;
     P.face_cells = tile_face_cells(ctx->L, ctx->tile_fz);
     P.sx = P.sy = P.sz = 1;
-    P.groups = 1;
+    P.nblocks = 1;
     for (int e = 0; e < TILE_MAX_ENT; e++) P.ent[e] = ctx->tile_ent[e];
     if (ctx->tile_blocks == 0) {
         hipDeviceProp_t prop;
@@ -95,6 +95,19 @@ static int prepare_tile_sweep(ttsweep_ctx *ctx)
 #endif
         ctx->tile_blocks = per_cu * std::max(prop.multiProcessorCount, 1);
     }
+    // the workgroups' private work sums: [tile_blocks][nstart][2], zero between solves
+    P.nblocks = ctx->tile_blocks;
+    P.nstart = ctx->stats.nstart;
+    const size_t need = (size_t)ctx->tile_blocks * (size_t)P.nstart * 2;
+    if (need > ctx->tile_wgwork_cap) {
+        if (ctx->d_tile_wgwork) HIPCHK(hipFree(ctx->d_tile_wgwork));
+        ctx->d_tile_wgwork = nullptr;
+        ctx->tile_wgwork_cap = 0;
+        HIPCHK(hipMalloc((void **)&ctx->d_tile_wgwork, need * sizeof(unsigned long long)));
+        ctx->tile_wgwork_cap = need;
+    }
+    HIPCHK(hipMemsetAsync(ctx->d_tile_wgwork, 0, need * sizeof(unsigned long long), ctx->stream));
+    P.wgwork = ctx->d_tile_wgwork;
     return 0;
 }
 
@@ -105,9 +118,8 @@ static int launch_pass_tile(ttsweep_ctx *ctx, int nactive, int *d_changed)
     TileSweep &P = ctx->tile_sweep;
     P.changed = d_changed;
     P.nactive = nactive;
-    // the resident grid, dealt evenly over the active starts (at least one workgroup each)
-    P.groups = std::max(ctx->tile_blocks / std::max(nactive, 1), 1);
-    P.groups = std::min(P.groups, P.NJ * P.NK);         // (no more workgroups than candidates)
+    // the resident grid (no more workgroups than candidates)
+    P.nblocks = (int)std::min<long long>(ctx->tile_blocks, (long long)P.NJ * P.NK * nactive);
     const int o = ctx->pass_index & 7;                  // the eight orderings in turn
     P.sx = (o & 1) ? -1 : 1;
     P.sy = (o & 2) ? -1 : 1;
@@ -176,7 +188,7 @@ int solve_device_body(ttsweep_ctx *ctx, int nstart, const ttsweep_start *starts,
         if (init) HIPCHK(launch_init_tt(L, sd.T, sd.sidx, ctx->stream));
         else HIPCHK(launch_pack(L, tt_dev[s], sd.T, INFINITY, ctx->stream));
         if (ctx->kernel == TTSWEEP_KERNEL_STRIP)
-            HIPCHK(launch_init_tile_flags(L, sd, /*from_box=*/!init, ctx->stream));
+            HIPCHK(launch_init_tile_flags(L, sd, /*from_box=*/!init, ctx->plans[np - 1].ra, np, ctx->stream));
         if (ctx->kernel == TTSWEEP_KERNEL_TILE) {
             HIPCHK(launch_init_tile_state(L, sd, /*from_box=*/!init, ctx->stream));
             float *const faces = ctx->d_tface + (size_t)s * tile_face_cells(L, ctx->tile_fz);
@@ -307,6 +319,8 @@ int solve_device_body(ttsweep_ctx *ctx, int nstart, const ttsweep_start *starts,
 
     for (int s = 0; s < nstart; s++)
         HIPCHK(launch_unpack(L, ctx->h_starts[s].T, tt_dev[s], ctx->stream));
+    if (ctx->kernel == TTSWEEP_KERNEL_TILE)
+        HIPCHK(launch_tile_reduce_work(ctx->d_tile_wgwork, ctx->tile_blocks, nstart, ctx->d_work, ctx->stream));
     HIPCHK(hipMemcpyAsync(ctx->h_work, ctx->d_work, 3 * nstart * sizeof(unsigned long long),
                           hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipEventRecord(ctx->ev_solve1, ctx->stream));

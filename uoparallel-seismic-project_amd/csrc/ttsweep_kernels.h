@@ -20,8 +20,9 @@ hipError_t launch_init_tt(const DevLayout &L, float *padded, long long sidx,
 // ---- device census / input check -------------------------------------------
 // *seen |= 1 << (XCD id) for every workgroup of an `nblocks`-workgroup launch
 hipError_t launch_xcc_census(unsigned *seen, int nblocks, hipStream_t st);
-// *bad += cells of the caller's n-cell velocity volume that are negative or not finite
-hipError_t launch_count_bad_velocity(const float *v, long long n, unsigned long long *bad, hipStream_t st);
+// *bad += cells of the caller's n-cell velocity volume that are negative, not finite, or
+// positive but below `tiny`
+hipError_t launch_count_bad_velocity(const float *v, long long n, float tiny, unsigned long long *bad, hipStream_t st);
 
 // ---- sweep, variant CELL ---------------------------------------------------
 // One chaotic in-place pull pass over the whole grid for the `nactive` starts
@@ -46,36 +47,35 @@ hipError_t launch_validate(const DevLayout &L, const float *v, const float *T, l
 // A pass = launch_plan_pass + launch_sweep_units, nothing else: the last workgroup of
 // sweep_units hands the "changed" words to the host and clears the counters (ctrl: the
 // UNITQ_CTRL_WORDS queue words + one "workgroups done" word, all zero before the first
-// pass) and the next pass's "changed" words.  `parity` =
-// pass index & 1 selects which half of StartDesc::tile_flags the pass writes.
+// pass) and the next pass's "changed" words.
 // plan_pass: one thread per entry of the static work list `work`: work[i] = (start index,
-// unit id = (a*btiles + bt)*cstrips + cs) or unit id < 0 for padding; entry i belongs to
-// XCD i % 8.  Decides which units are due in this pass (activity flags of the previous
-// pass, distance gate, held-back plane bits), appends (start, unit, planes) to the queue of
-// the unit's XCD and clears the unit's flag word of this pass.
+// unit id = (A*btiles + bt)*cstrips + cs) or unit id < 0 for padding; entry i belongs to
+// XCD i % nlists.  A unit is due when its pend word holds staged-plane bits (pushed by the
+// units that improved those planes: push_improved) and the distance gate has reached it; due
+// units are appended as (start, unit, planes) to the queue of their XCD, their word cleared.
 // sweep_units: a persistent grid (`nblocks` workgroups) drains the queues, own XCD first.
 size_t units_lds_bytes(const StripPlan &plan, int nb);
 int units_wgs_per_cu();     // persistent workgroups per CU the unit kernel is built for
 hipError_t launch_plan_pass(const DevLayout &L, const StartDesc *starts, const int2 *work,
                             long long nwork, int *changed, int4 *lists, int list_cap, int nlists,
-                            int *ctrl, const StripPlan &plan, int parity, float gate_r2, hipStream_t st);
+                            int *ctrl, const StripPlan &plan, float gate_r2, hipStream_t st);
 hipError_t launch_sweep_units(const DevLayout &L, const float *v, const StartDesc *starts,
                               const int4 *lists, int list_cap, int nlists, int *ctrl, int nblocks,
                               int *changed, const StripItem *items, const StripPlan &plan,
-                              int parity, const UnitPassTail &tail, hipStream_t st);
-// First activity flags of a start: from_box = false: only the start's unit is a source;
-// from_box = true: every unit that holds a finite travel time is one.
-hipError_t launch_init_tile_flags(const DevLayout &L, const StartDesc &sd, bool from_box,
+                              const UnitPassTail &tail, hipStream_t st);
+// First activity words of a start: from_box = false: only the start's patch is a source;
+// from_box = true: every patch that holds a finite travel time is one.  (ra, np: the reach of
+// the star along the plane axis and the planes per unit of the solve.)
+hipError_t launch_init_tile_flags(const DevLayout &L, const StartDesc &sd, bool from_box, int ra, int np,
                                   hipStream_t st);
 
 // ---- sweep, variant TILE ---------------------------------------------------
 // One call = the tiles of one hyperplane of an ordering sweep (TileSweep), ONE kernel: a grid of
-// P.groups single-wavefront workgroups per active start (in all at most what
-// tile_sweep_wgs_per_cu says the device holds at once, unless there are more starts than that);
-// workgroup (start, g) evaluates the candidates g, g + groups, ... of its start - a tile is
-// relaxed only if one of its 27 neighbours improved since it was last relaxed
-// (StartDesc::tile_flags holds two words per tile) - and relaxes the due ones; the starts' work
-// counters get one pair of atomics per workgroup.  A sweep = the calls D = 0 .. NI + NJ + NK - 3
+// P.nblocks single-wavefront workgroups (what tile_sweep_wgs_per_cu says the device holds at
+// once); workgroup b evaluates the candidates (active start, J', K') number b, b + nblocks, ...
+// - a tile is relaxed only if one of its 27 neighbours improved since it was last relaxed
+// (StartDesc::tile_flags holds two words per tile) - and relaxes the due ones; its work sums go
+// to private slots (P.wgwork) that launch_tile_reduce_work adds to the starts' counters.  A sweep = the calls D = 0 .. NI + NJ + NK - 3
 // in stream order.  changed[s] |= 1 when a tile of start s improved: a whole sweep without a
 // change proves convergence.
 size_t tile_lds_bytes(int R);
@@ -85,6 +85,8 @@ hipError_t launch_build_tile_faces(const DevLayout &L, const float *padded, floa
 hipError_t launch_init_tile_faces(const DevLayout &L, float *faces, int fz, int sa, int sb, int sc, hipStream_t st);
 hipError_t tile_sweep_wgs_per_cu(const TileSweep &P, int *wgs);
 hipError_t launch_tile_sweep(const TileSweep &P, hipStream_t st);
+// work0[3 s], work0[3 s + 2] += the workgroups' private sums wgwork[block][s][0 / 1]; slots cleared
+hipError_t launch_tile_reduce_work(unsigned long long *wgwork, int nblocks, int nstart, unsigned long long *work0, hipStream_t st);
 // from_box = false: only the start's tile counts as changed; true: every tile does.
 hipError_t launch_init_tile_state(const DevLayout &L, const StartDesc &sd, bool from_box, hipStream_t st);
 

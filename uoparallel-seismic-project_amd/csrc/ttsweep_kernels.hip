@@ -12,6 +12,7 @@
 
 #include <algorithm>
 #include <cstdlib>
+#include <cstring>
 
 namespace ttsweep {
 
@@ -166,27 +167,34 @@ hipError_t launch_xcc_census(unsigned *seen, int nblocks, hipStream_t st)
     return hipGetLastError();
 }
 
-// Cells of the caller's velocity volume that are negative, infinite or NaN (the relaxation
-// needs delays >= 0; a NaN would also defeat the kernels' NaN-free
-// arithmetic mode; zero - either sign - is accepted as the reference accepts it).  Integer
-// test on the bit pattern: this file is compiled with -fno-honor-nans.
+// Cells of the caller's velocity volume the solver refuses: negative, infinite or NaN (the
+// relaxation needs delays >= 0; a NaN would also defeat the kernels'
+// NaN-free arithmetic mode), and positive values below `tiny_bits` (as a bit pattern): so small
+// that a delay fl(d * (v[c] + v[o])) could fall into the denormal range, where halving is no
+// longer exact - the reference halves the rounded product (serial_new/...:216: "/ 2.0"), the
+// kernels multiply by d/2, and the two agree bit for bit only while the product is a normal
+// number (or zero).  Zero - either sign - is accepted as the reference accepts it.  Integer
+// tests on the bit pattern: this file is compiled with -fno-honor-nans.
 __global__ void __launch_bounds__(256)
-count_bad_velocity_kernel(const float *__restrict__ v, long long n, unsigned long long *__restrict__ bad)
+count_bad_velocity_kernel(const float *__restrict__ v, long long n, unsigned tiny_bits, unsigned long long *__restrict__ bad)
 {
     unsigned mine = 0;
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
         const unsigned bits = __float_as_uint(v[i]);
-        mine += !(bits < 0x7f800000u || bits == 0x80000000u);
+        const bool ok = bits == 0u || bits == 0x80000000u || (bits >= tiny_bits && bits < 0x7f800000u);
+        mine += !ok;
     }
 #pragma unroll
     for (int w = 32; w >= 1; w >>= 1) mine += __shfl_xor(mine, w);
     if ((threadIdx.x & 63) == 0 && mine) atomicAdd(bad, (unsigned long long)mine);
 }
 
-hipError_t launch_count_bad_velocity(const float *v, long long n, unsigned long long *bad, hipStream_t st)
+hipError_t launch_count_bad_velocity(const float *v, long long n, float tiny, unsigned long long *bad, hipStream_t st)
 {
     const unsigned nblocks = (unsigned)std::min<long long>((n + 255) / 256, 4096);
-    hipLaunchKernelGGL(count_bad_velocity_kernel, dim3(nblocks), dim3(256), 0, st, v, n, bad);
+    unsigned tiny_bits = 1u;            // (every positive number)
+    if (tiny > 0.0f) memcpy(&tiny_bits, &tiny, sizeof tiny_bits);
+    hipLaunchKernelGGL(count_bad_velocity_kernel, dim3(nblocks), dim3(256), 0, st, v, n, tiny_bits, bad);
     return hipGetLastError();
 }
 
@@ -654,7 +662,10 @@ init_tile_flags_box_kernel(DevLayout L, const float *__restrict__ T, int *__rest
     }
 }
 
-hipError_t launch_init_tile_flags(const DevLayout &L, const StartDesc &sd, bool from_box, hipStream_t st)
+__global__ void seed_pend_kernel(DevLayout L, int *__restrict__ tile_flags, int nflag, int ra, int np, int btiles,
+                                 int cstrips, int nunits);      // (below, next to push_improved)
+
+hipError_t launch_init_tile_flags(const DevLayout &L, const StartDesc &sd, bool from_box, int ra, int np, hipStream_t st)
 {
     const int btiles = strip_btiles(L), cstrips = strip_cstrips(L);
     const int nflag = strip_flag_words(L);
@@ -663,11 +674,14 @@ hipError_t launch_init_tile_flags(const DevLayout &L, const StartDesc &sd, bool 
         if (e != hipSuccess) return e;
         hipLaunchKernelGGL(init_tile_flags_box_kernel, dim3(nflag), dim3(64), 0, st, L, sd.T,
                            sd.tile_flags, nflag, btiles, cstrips);
-        return hipGetLastError();
+    } else {
+        const int start_flag = (sd.sa * btiles + sd.sb / STRIP_TB) * cstrips + sd.sc / STRIP_K;
+        hipLaunchKernelGGL(init_tile_flags_kernel, dim3((nflag + 255) / 256), dim3(256), 0, st,
+                           sd.tile_flags, nflag, start_flag);
     }
-    const int start_flag = (sd.sa * btiles + sd.sb / STRIP_TB) * cstrips + sd.sc / STRIP_K;
-    hipLaunchKernelGGL(init_tile_flags_kernel, dim3((nflag + 255) / 256), dim3(256), 0, st,
-                       sd.tile_flags, nflag, start_flag);
+    const int nunits = strip_units(L, np);
+    hipLaunchKernelGGL(seed_pend_kernel, dim3((nunits + 255) / 256), dim3(256), 0, st, L, sd.tile_flags, nflag, ra, np,
+                       btiles, cstrips, nunits);
     return hipGetLastError();
 }
 
@@ -676,11 +690,11 @@ hipError_t launch_init_tile_flags(const DevLayout &L, const StartDesc &sd, bool 
 // ---------------------------------------------------------------------------
 //
 // Activity tracking.  A unit's offsets against staged plane q have to be relaxed in a pass
-// only if a unit they read from (the plane pair holding q, +-1 lane tile, +-1 strip)
-// improved in the previous pass: everything else was already relaxed against unchanged
-// values.  Every unit has a flag word per pass parity (where it improved, by border zone:
-// see flag_bit), so that a neighbouring strip or lane tile reacts only to improvements
-// within its reach.
+// only if a patch they read from (plane q, +-1 lane tile, +-1 strip) improved since the unit
+// last relaxed against it: everything else was already relaxed against unchanged values.
+// Whoever improves a patch tells the units that stage it (push_improved: one bit per staged
+// plane in the unit's pend word), by border zone (flag_bit), so that a neighbouring strip or
+// lane tile reacts only to improvements within its reach.
 //
 // Distance gate.  Far from the start the first values to arrive (over long edges) are
 // poor and get refined pass after pass; relaxing those units early is wasted work.  A unit
@@ -699,12 +713,70 @@ hipError_t launch_init_tile_flags(const DevLayout &L, const StartDesc &sd, bool 
 // at a time, its four waves splitting the items of every staged plane among themselves
 // (nearly equal shares, StripPlan::wsplit) and min-combining their partial results through LDS.
 
+// ---- who has to look again ----------------------------------------------------------------
+// pend[unit] (third block of StartDesc::tile_flags): bit p set = staged plane p of the unit
+// changed since the unit last relaxed against it (or the unit was held back by the gate with
+// that bit set).  The bits are PUSHED by whoever improves a plane: the patch (plane a, lane
+// tile bt, strip cs) that improved sets bit a - (np A' - ra) of every unit (A', bt', cs') that
+// stages plane a from it - at most (2 ra + np) / np + 1 plane groups x 3 lane tiles x 3 strips,
+// a lane each, atomicOr without return - where a neighbouring lane tile / strip counts only if
+// the improvement lay within reach of the shared border (flag_bit).  The planner then reads
+// ONE word per unit (round 2: it gathered 9 flag words per staged plane, 144 per unit of two
+// planes, in every pass).
+template <int NP>
+__device__ __forceinline__ void push_improved(const DevLayout &L, int ra, int btiles, int cstrips,
+                                              unsigned *__restrict__ pend, int a, int bt, int cs, int improved, int lane)
+{
+    const int lo_num = a - ra - NP + 1;                                 // A' >= ceil(lo_num / NP)
+    const int Alo = max(NP == 1 ? lo_num : (lo_num + 1) >> 1, 0);
+    const int Ahi = min((a + ra) / NP, strip_agroups(L, NP) - 1);
+    const int n = (Ahi - Alo + 1) * 9;
+    for (int idx = lane; idx < n; idx += 64) {
+        const int A = Alo + idx / 9, r = idx % 9;
+        const int db = r / 3 - 1, dc = r % 3 - 1;
+        const int nb = bt + db, nc = cs + dc;
+        // the unit above / behind reads across our high border: our HI zone matters to it
+        const int need = flag_bit(db == 1 ? ZONE_HI : db == -1 ? ZONE_LO : ZONE_ANY,
+                                  dc == 1 ? ZONE_HI : dc == -1 ? ZONE_LO : ZONE_ANY);
+        if (nb >= 0 && nb < btiles && nc >= 0 && nc < cstrips && (improved & need))
+            atomicOr(&pend[(A * btiles + nb) * cstrips + nc], 1u << (a - (NP * A - ra)));
+    }
+}
+
+// First pend words of a start, from the patch flags the initialisation kernels leave in the
+// second flag block (the start's patch, or every patch that holds a finite value): one thread
+// per unit, the rule of push_improved read backwards.
+__global__ void __launch_bounds__(256)
+seed_pend_kernel(DevLayout L, int *__restrict__ tile_flags, int nflag, int ra, int np, int btiles, int cstrips, int nunits)
+{
+    const int unit = blockIdx.x * 256 + threadIdx.x;
+    if (unit >= nunits) return;
+    int u = unit;
+    const int cs = u % cstrips;  u /= cstrips;
+    const int bt = u % btiles;   u /= btiles;
+    const int a0 = np * u;
+    const int *__restrict__ flags = tile_flags + nflag;
+    unsigned planes = 0;
+    for (int p = 0; p < 2 * ra + np; p++) {
+        const int q = a0 - ra + p;
+        if (q < 0 || q >= L.n[0]) continue;
+        for (int r = 0; r < 9; r++) {
+            const int nb = bt + r / 3 - 1, nc = cs + r % 3 - 1;
+            const int need = flag_bit(r / 3 == 0 ? ZONE_HI : r / 3 == 2 ? ZONE_LO : ZONE_ANY,
+                                      r % 3 == 0 ? ZONE_HI : r % 3 == 2 ? ZONE_LO : ZONE_ANY);
+            if (nb >= 0 && nb < btiles && nc >= 0 && nc < cstrips && (flags[(q * btiles + nb) * cstrips + nc] & need))
+                planes |= 1u << p;
+        }
+    }
+    reinterpret_cast<unsigned *>(tile_flags + 2 * nflag)[unit] = planes;
+}
+
 struct PlaneCounts { int n[STRIP_STAGED][STRIP_PLANES]; };     // StripPlan::nent (offsets per staged plane and own plane)
 
 __global__ void __launch_bounds__(256)
 plan_pass_kernel(DevLayout L, const StartDesc *__restrict__ starts, const int2 *__restrict__ work,
                  long long nwork, int *__restrict__ changed, int4 *__restrict__ lists, int list_cap,
-                 int *__restrict__ ctrl, int nlists, int ra, int np, int btiles, int cstrips, int parity,
+                 int *__restrict__ ctrl, int nlists, int ra, int np, int btiles, int cstrips,
                  float gate_r2, PlaneCounts pc)
 {
     // wave W handles 64 consecutive entries of ONE XCD's sub-list, so that a wave-level
@@ -728,24 +800,11 @@ plan_pass_kernel(DevLayout L, const StartDesc *__restrict__ starts, const int2 *
         const int cs = u % cstrips;  u /= cstrips;
         const int bt = u % btiles;   u /= btiles;
         const int a0 = np * u;                  // first own plane
-        const int *__restrict__ prev_flags = sd.tile_flags + (1 - parity) * nflag;
-        for (int p = 0; p < 2 * ra + np; p++) {
-            const int q = a0 - ra + p;          // staged plane
-            if (q < 0 || q >= L.n[0]) continue;
-            bool due = false;
-            for (int r = 0; r < 9; r++) {
-                const int nb = bt + r / 3 - 1, nc = cs + r % 3 - 1;
-                // the neighbour below / before reads across our low border: its HI zone matters
-                const int need = flag_bit(r / 3 == 0 ? ZONE_HI : r / 3 == 2 ? ZONE_LO : ZONE_ANY,
-                                          r % 3 == 0 ? ZONE_HI : r % 3 == 2 ? ZONE_LO : ZONE_ANY);
-                if (nb >= 0 && nb < btiles && nc >= 0 && nc < cstrips
-                    && (prev_flags[(q * btiles + nb) * cstrips + nc] & need))
-                    due = true;
-            }
-            if (due) planes |= 1u << p;
-        }
-        // distance gate and held-back plane bits
+        // staged planes that changed since this unit last relaxed against them, and plane
+        // bits it was held back with (push_improved, seed_pend_kernel)
         unsigned *__restrict__ pend = reinterpret_cast<unsigned *>(sd.tile_flags + 2 * nflag);
+        planes = pend[unit];
+        // distance gate
         const int b0 = bt * STRIP_TB, cb0 = cs * STRIP_K;
         const int tb_eff = min(STRIP_TB, L.n[1]);
         const float da_ = (float)max(max(a0 - sd.sa, sd.sa - (a0 + np - 1)), 0);
@@ -753,17 +812,12 @@ plan_pass_kernel(DevLayout L, const StartDesc *__restrict__ starts, const int2 *
         const float dc_ = (float)max(max(cb0 - sd.sc, sd.sc - (cb0 + STRIP_K - 1)), 0);
         const bool gated = sd.tile_flags[3 * nflag] == 1;
         const bool open = !gated || da_ * da_ + db_ * db_ + dc_ * dc_ <= gate_r2;
-        const unsigned held = pend[unit];
         if (!open) {
-            if (planes & ~held) pend[unit] = held | planes;
-            if (held | planes) atomicOr(&changed[s], CHANGED_PENDING);     // work is waiting
+            if (planes) atomicOr(&changed[s], CHANGED_PENDING);     // work is waiting (the bits stay)
             planes = 0;
-        } else {
-            planes |= held;
-            if (held) pend[unit] = 0;
+        } else if (planes) {
+            pend[unit] = 0;         // (no unit kernel runs beside the planner: a plain store)
         }
-        for (int j = 0; j < np; j++)                    // improvements of this pass are OR-ed in
-            if (a0 + j < L.n[0]) sd.tile_flags[parity * nflag + ((a0 + j) * btiles + bt) * cstrips + cs] = 0;
     }
     const unsigned long long due_lanes = __ballot(planes != 0);
     if (due_lanes == 0ull) return;
@@ -815,7 +869,7 @@ __device__ __forceinline__ void relax_special_cell(const DevLayout &L, const flo
                                                    const StartDesc &sd, int s, int cell,
                                                    int *__restrict__ changed,
                                                    const CellEntry *__restrict__ entries,
-                                                   int nentries, int parity, int lane)
+                                                   int nentries, int ra, int np, int lane)
 {
     const int ea = sd.box_hi[0] - sd.box_lo[0] + 1;
     const int eb = sd.box_hi[1] - sd.box_lo[1] + 1;
@@ -857,12 +911,16 @@ __device__ __forceinline__ void relax_special_cell(const DevLayout &L, const flo
     }
 #pragma unroll
     for (int w = 32; w >= 1; w >>= 1) best = fminf(best, __shfl_xor(best, w));
-    if (lane == 0 && best < told) {
+    const bool better = best < told;        // (wave-uniform: `best` is the wave's minimum)
+    if (lane == 0 && better) {
         T[ci] = best;
         atomicOr(&changed[s], CHANGED_IMPROVED);
+    }
+    if (better) {
         const int btiles = strip_btiles(L), cstrips = strip_cstrips(L);
-        atomicOr(sd.tile_flags + parity * strip_flag_words(L)
-                 + (a * btiles + b / STRIP_TB) * cstrips + c / STRIP_K, FLAG_ALL);
+        unsigned *const pend = reinterpret_cast<unsigned *>(sd.tile_flags + 2 * strip_flag_words(L));
+        if (np == 1) push_improved<1>(L, ra, btiles, cstrips, pend, a, b / STRIP_TB, c / STRIP_K, FLAG_ALL, lane);
+        else push_improved<2>(L, ra, btiles, cstrips, pend, a, b / STRIP_TB, c / STRIP_K, FLAG_ALL, lane);
     }
 }
 
@@ -936,9 +994,6 @@ void prof_dump()
 #define PROF_T(x)
 #endif
 
-#ifndef TTSWEEP_SLABS
-#define TTSWEEP_SLABS 2             // slabs in LDS: 2 = the next plane loads while this one is relaxed; 3 = the next two
-#endif
 #ifndef TTSWEEP_WGS_PER_CU
 #define TTSWEEP_WGS_PER_CU 2        // persistent workgroups per CU (measured optimum)
 #endif
@@ -952,7 +1007,7 @@ __global__ void __launch_bounds__(STRIP_TB *STRIP_NS, TTSWEEP_WGS_PER_CU)
 sweep_units_kernel(DevLayout L, const float *__restrict__ v, const StartDesc *__restrict__ starts,
                    const int4 *__restrict__ lists, int list_cap, int nlists, int *__restrict__ ctrl,
                    int *__restrict__ changed, const StripItem *__restrict__ items, StripPlan plan,
-                   int btiles, int cstrips, int parity, UnitPassTail tail)
+                   int btiles, int cstrips, UnitPassTail tail)
 {
     constexpr int NS = STRIP_NS;
     constexpr int W = K + 2 * STRIP_CF;
@@ -999,7 +1054,7 @@ sweep_units_kernel(DevLayout L, const float *__restrict__ v, const StartDesc *__
         const int s = tail.active[w / tail.max_box_cells];
         const StartDesc sd = starts[s];
         relax_special_cell(L, v, sd, s, w % tail.max_box_cells, changed, tail.entries, tail.nentries,
-                           parity, lane);
+                           plan.ra, NP, lane);
     }
 
     PROF_T(t_k0);
@@ -1088,17 +1143,6 @@ sweep_units_kernel(DevLayout L, const float *__restrict__ v, const StartDesc *__
 #pragma unroll
             for (int p = 0; p < K / 2 - 1; p++) vco[jp][p] = f32x2{vce[jp][p].y, vce[jp][p + 1].x};
         }
-#if TTSWEEP_SLABS == 3
-        // (three slabs: the plane after the first one starts to load as well - behind the own
-        // cells' loads, so that the first wait below, which lets this wave's newest LDS-DMA
-        // instructions stay in flight, does not wait for it)
-        if (todo & (todo - 1)) {
-            const long long src = src0 + (long long)__builtin_ctz(todo & (todo - 1)) * L.s0;
-            stage_slab(v + src, T + src, s1_bytes, slabs + slab_floats, rows, rows8, wave, lane);
-        }
-        // LDS-DMA instructions this wave issues per slab (stage_slab: groups wave, wave + NS, ... of both arrays)
-        const int my_dma = rows8 / 8 > wave ? 2 * ((rows8 / 8 - wave + NS - 1) / NS) : 0;
-#endif
         // what this wave will finish and store at the end: CQ consecutive cells of one own
         // plane; their values before this unit's relaxation stay in registers
         constexpr int CQ = NP * K / NS;     // cells per wave in the epilogue
@@ -1123,23 +1167,6 @@ sweep_units_kernel(DevLayout L, const float *__restrict__ v, const StartDesc *__
             const int next_first = todo
                 ? min(__builtin_amdgcn_readfirstlane(item_range[wave * 16 + __builtin_ctz(todo)]) & 0xffff, nitems - 1)
                 : 0;
-#if TTSWEEP_SLABS == 3
-            // this wave's part of slab `p` has landed (the loads of the plane after it, issued
-            // later, may still be in flight: loads complete in order) ...
-            if (todo == 0 || my_dma == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            else if (my_dma == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-            else if (my_dma == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-            else if (my_dma == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            // ... and so has everybody else's; the slab of the previous plane is no longer read
-            __syncthreads();
-            PROF_T(t1);
-            // the plane after the next one loads into that slab while this one is relaxed
-            if (todo & (todo - 1)) {
-                const long long src = src0 + (long long)__builtin_ctz(todo & (todo - 1)) * L.s0;
-                stage_slab(v + src, T + src, s1_bytes, slabs + ((buf + 2) % 3) * slab_floats, rows, rows8, wave, lane);
-            }
-#else
             // this wave's part of slab `p` has landed ...
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             // ... and so has everybody else's; the other slab is no longer read
@@ -1150,7 +1177,6 @@ sweep_units_kernel(DevLayout L, const float *__restrict__ v, const StartDesc *__
                 const long long src = src0 + (long long)__builtin_ctz(todo) * L.s0;
                 stage_slab(v + src, T + src, s1_bytes, slabs + (buf ^ 1) * slab_floats, rows, rows8, wave, lane);
             }
-#endif
             PROF_T(t2);
 #ifdef TTSWEEP_PROFILE
             p_wait += t1 - t0; p_stage += t2 - t1;
@@ -1186,11 +1212,7 @@ sweep_units_kernel(DevLayout L, const float *__restrict__ v, const StartDesc *__
                 cur = nxt;
             }
             if (ibeg >= iend) cur = load_hdr(items, next_first);    // (no item of this plane was ours)
-#if TTSWEEP_SLABS == 3
-            buf = buf == 2 ? 0 : buf + 1;
-#else
             buf ^= 1;
-#endif
 #ifdef TTSWEEP_PROFILE
             p_comp += clock64() - t2;
 #endif
@@ -1236,10 +1258,11 @@ sweep_units_kernel(DevLayout L, const float *__restrict__ v, const StartDesc *__
         }
 #pragma unroll
         for (int w = 32; w >= 1; w >>= 1) improved |= __shfl_xor(improved, w);
-        if (lane == 0 && improved) {
-            atomicOr(tile_flags + parity * nflag + (a * btiles + bt) * cstrips + cs, improved);
+        if (improved) {         // (wave-uniform) the units that stage this plane have to look again
+            push_improved<NP>(L, plan.ra, btiles, cstrips, reinterpret_cast<unsigned *>(tile_flags + 2 * nflag),
+                              a, bt, cs, improved, lane);
             // (the start's word: once per wave, start and pass - its few words are a hot spot)
-            if (s != flagged) atomicOr(&changed[s], CHANGED_IMPROVED);
+            if (lane == 0 && s != flagged) atomicOr(&changed[s], CHANGED_IMPROVED);
             flagged = s;
         }
 #ifdef TTSWEEP_PROFILE
@@ -1289,14 +1312,14 @@ sweep_units_kernel(DevLayout L, const float *__restrict__ v, const StartDesc *__
 size_t units_lds_bytes(const StripPlan &plan, int nb)
 {
     (void)plan; (void)nb;
-    size_t floats = (size_t)TTSWEEP_SLABS * SLAB_BYTES / 4;                 // the slabs of v and T rows
+    size_t floats = (size_t)2 * SLAB_BYTES / 4;                             // two slabs of v and T rows
     floats = std::max(floats, (size_t)STRIP_NS * STRIP_PLANES * STRIP_K * STRIP_TB);    // combine buffer
     return (floats + STRIP_LDS_HEAD) * sizeof(float);
 }
 
 hipError_t launch_plan_pass(const DevLayout &L, const StartDesc *starts, const int2 *work,
                             long long nwork, int *changed, int4 *lists, int list_cap, int nlists,
-                            int *ctrl, const StripPlan &plan, int parity, float gate_r2, hipStream_t st)
+                            int *ctrl, const StripPlan &plan, float gate_r2, hipStream_t st)
 {
     if (nwork <= 0) return hipSuccess;
     if (nlists < 1 || nlists > UNITQ_LISTS) return hipErrorInvalidValue;
@@ -1311,14 +1334,14 @@ hipError_t launch_plan_pass(const DevLayout &L, const StartDesc *starts, const i
         for (int j = 0; j < STRIP_PLANES; j++) pc.n[p][j] = p < plan.nstaged ? plan.nent[p][j] : 0;
     hipLaunchKernelGGL(plan_pass_kernel, dim3((unsigned)nblocks), dim3(256), 0, st, L, starts, work,
                        nwork, changed, lists, list_cap, ctrl, nlists, plan.ra, plan.np, btiles, strip_cstrips(L),
-                       parity, gate_r2, pc);
+                       gate_r2, pc);
     return hipGetLastError();
 }
 
 hipError_t launch_sweep_units(const DevLayout &L, const float *v, const StartDesc *starts,
                               const int4 *lists, int list_cap, int nlists, int *ctrl, int nblocks,
                               int *changed, const StripItem *items, const StripPlan &plan,
-                              int parity, const UnitPassTail &tail, hipStream_t st)
+                              const UnitPassTail &tail, hipStream_t st)
 {
     if (nblocks <= 0 || nlists < 1 || nlists > UNITQ_LISTS)
         return hipErrorInvalidValue;                    // (the last workgroup closes the pass)
@@ -1332,7 +1355,7 @@ hipError_t launch_sweep_units(const DevLayout &L, const float *v, const StartDes
         if (e != hipSuccess) return e;
     }
     hipLaunchKernelGGL(kern, dim3((unsigned)nblocks), dim3(STRIP_TB, STRIP_NS), lds, st, L, v, starts,
-                       lists, list_cap, nlists, ctrl, changed, items, plan, btiles, strip_cstrips(L), parity, tail);
+                       lists, list_cap, nlists, ctrl, changed, items, plan, btiles, strip_cstrips(L), tail);
     return hipGetLastError();
 }
 

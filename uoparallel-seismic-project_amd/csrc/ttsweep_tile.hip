@@ -150,28 +150,32 @@ __device__ __forceinline__ T *uni_ptr(T *p)
 // planning inside the sweep kernels: which tiles of hyperplane D are due
 // ---------------------------------------------------------------------------
 // A launch relaxes the due tiles of ONE hyperplane D for every active start; there is no
-// separate planning kernel and no list (round 2 had both: 5.8 us of planner and a second
-// kernel boundary in front of every one of the ~5700 launches of a solve).  The grid is
-// G workgroups per active start; workgroup (start, g) owns the candidates (J', K') with linear
-// index g, g + G, g + 2 G, ... of its start - round-robin, so that a spatial cluster of due
-// tiles spreads over the workgroups - evaluates up to 64 of them at a time, one per lane (the
-// tile's two stamps, one 8-byte load), and then relaxes the due ones in turn.  A tile is due
-// when one of its 27 neighbours (itself included) improved in or after the epoch it was last
-// relaxed in (they stamp its y word when they do: tile_stamp_neighbours).
-// Tiles of the same hyperplane may improve while a workgroup is still evaluating: it then
-// either sees the new stamp (and relaxes a tile that would have been due in the next sweep
-// anyway) or does not (the stamp is >= the tile's own, so the tile is due in a later launch):
-// nothing is ever skipped for good.
+// separate planning kernel and no list (round 2 had both: a planner kernel and a second kernel
+// boundary in front of every one of the ~5700 launches of a solve).  The candidates of a launch
+// are the pairs (active start, (J', K')), NJ * NK * nactive of them; workgroup b owns candidates
+// b, b + grid, b + 2 grid, ... - round-robin over ALL starts, so that the load of a workgroup is
+// the launch's average whatever start the due tiles belong to and wherever they cluster -,
+// evaluates up to 64 of them at a time, one per lane (the tile's two stamps, one 8-byte load),
+// and then relaxes the due ones in turn.  A tile is due when one of its 27 neighbours (itself
+// included) improved in or after the epoch it was last relaxed in (they stamp its y word when
+// they do: tile_stamp_neighbours).  Tiles of the same hyperplane may improve while a workgroup
+// is still evaluating: it then either sees the new stamp (and relaxes a tile that would have
+// been due in the next sweep anyway) or does not (the stamp is >= the tile's own, so the tile is
+// due in a later launch): nothing is ever skipped for good.
 struct TileCand {
+    int a;              // index into the active list
     int tile;           // (I * NJ + J) * NK + K
     unsigned cells;     // cells of the tile inside the grid
     bool due;
 };
 
-__device__ __forceinline__ TileCand tile_candidate(const TileSweep &P, int2 *__restrict__ state, int c, int ncand)
+__device__ __forceinline__ TileCand tile_candidate(const TileSweep &P, long long t, int ncand)
 {
-    TileCand r{0, 0u, false};
-    if (c >= ncand) return r;
+    TileCand r{0, 0, 0u, false};
+    if (t >= (long long)ncand * P.nactive) return r;
+    r.a = (int)(t / ncand);
+    const int c = (int)(t - (long long)r.a * ncand);
+    int2 *__restrict__ state = reinterpret_cast<int2 *>(P.state0 + (long long)P.active[r.a] * P.state_stride);
     const int Kp = c % P.NK, Jp = c / P.NK;
     const int Ip = P.D - Jp - Kp;
     if (Ip < 0 || Ip >= P.NI) return r;
@@ -221,16 +225,78 @@ void tile_prof_dump()
 // few hundred cycles instead of a vector-memory round trip per tile.
 typedef const __attribute__((address_space(4))) StartDesc *const_start_ptr;
 
-// The work counters of a start (relaxations, tiles): one pair of atomics per workgroup and
-// launch, after its last tile (10^4 workgroups adding per TILE to the same few words held every
-// tile up: 22 of 60 ms of a full sweep on 1024x1024x512 x 14 starts in round 2).
-__device__ __forceinline__ void tile_work_add(const TileSweep &P, int s, unsigned long long cells, unsigned tiles, int lane)
+// The work counters of the starts (relaxations, tiles).  10^4 workgroups adding per TILE to the
+// same few words held every tile up (22 of 60 ms of a full sweep on 1024x1024x512 x 14 starts
+// in round 2), and a workgroup now relaxes tiles of every start.  So lane a % 64 of a workgroup
+// keeps the sums of active start a in registers, and at the workgroup's end adds them to a slot
+// of its own (P.wgwork[block][a % 64]: no other writer in this launch, no atomics); the solve
+// reduces the slots once, at its end (tile_reduce_work).  Active indices 64 apart share a lane:
+// the lane flushes when the start it counts for changes (a workgroup's tiles come sorted by start).
+struct TileWork {
+    unsigned long long cells = 0;
+    unsigned tiles = 0;
+    int a = -1;         // active index this lane currently counts for
+    bool improved = false;      // a tile of that start improved in this launch
+};
+
+__device__ __forceinline__ void tile_work_flush(const TileSweep &P, TileWork &w)
 {
-    if (lane == 0 && tiles) {
-        unsigned long long *const work = P.work0 + 3 * s;
-        atomicAdd(work, cells * (unsigned long long)P.nent);
-        atomicAdd(work + 2, (unsigned long long)tiles);
+    if (w.a >= 0 && w.tiles) {
+        const int s = P.active[w.a];
+        unsigned long long *const slot = P.wgwork + ((size_t)blockIdx.x * P.nstart + s) * 2;
+        slot[0] += w.cells * (unsigned long long)P.nent;
+        slot[1] += w.tiles;
+        // (the start's "improved" word: a plain store of the one value this kernel ever writes
+        // there, once per workgroup and start, after its last tile - a store per improved tile to
+        // the starts' few words sits in front of the next tile's vmcnt(0) wait and, with
+        // thousands of workgroups storing, tripled the time of the sweeps in which every tile
+        // improves)
+        if (w.improved) P.changed[s] = CHANGED_IMPROVED;
     }
+    w.cells = 0; w.tiles = 0; w.improved = false;
+}
+
+// a tile of active start `a` improved
+__device__ __forceinline__ void tile_work_improved(TileWork &w, int a, int lane)
+{
+    if (lane == (a & 63)) w.improved = true;    // (tile_work_count has set w.a = a for this tile)
+}
+
+__device__ __forceinline__ void tile_work_count(const TileSweep &P, TileWork &w, int a, unsigned cells, int lane)
+{
+    if (lane == (a & 63)) {
+        if (w.a != a) { tile_work_flush(P, w); w.a = a; }
+        w.cells += cells;
+        w.tiles++;
+    }
+}
+
+// wgwork[block][start] -> the starts' work counters (one workgroup per start), slots cleared
+__global__ void __launch_bounds__(256)
+tile_reduce_work_kernel(unsigned long long *__restrict__ wgwork, int nblocks, int nstart, unsigned long long *__restrict__ work0)
+{
+    const int s = blockIdx.x;
+    unsigned long long cells = 0, tiles = 0;
+    for (int b = threadIdx.x; b < nblocks; b += 256) {
+        unsigned long long *const slot = wgwork + ((size_t)b * nstart + s) * 2;
+        cells += slot[0]; tiles += slot[1];
+        slot[0] = 0; slot[1] = 0;
+    }
+    __shared__ unsigned long long red[2][256];
+    red[0][threadIdx.x] = cells; red[1][threadIdx.x] = tiles;
+    __syncthreads();
+    for (int w = 128; w >= 1; w >>= 1) {
+        if ((int)threadIdx.x < w) { red[0][threadIdx.x] += red[0][threadIdx.x + w]; red[1][threadIdx.x] += red[1][threadIdx.x + w]; }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) { work0[3 * s] += red[0][0]; work0[3 * s + 2] += red[1][0]; }
+}
+
+hipError_t launch_tile_reduce_work(unsigned long long *wgwork, int nblocks, int nstart, unsigned long long *work0, hipStream_t st)
+{
+    if (nstart <= 0 || nblocks <= 0) return hipSuccess;
+    hipLaunchKernelGGL(tile_reduce_work_kernel, dim3(nstart), dim3(256), 0, st, wgwork, nblocks, nstart, work0);
+    return hipGetLastError();
 }
 
 // The 6-neighbour star with halo 1, entries in the pull star's order (sorted by offset):
@@ -280,22 +346,19 @@ tile_sweep_kernel(TileSweep P)
     PROF_STAMP(t_begin);
     // (everything that selects the tile is kept in scalar registers: the start descriptor then
     // comes through the scalar cache and the buffer descriptors need no waterfall loop)
-    const int G = uni(P.groups), g = uni((int)blockIdx.x % P.groups);
-    const int s = uni(P.active[blockIdx.x / P.groups]);
-    int2 *const state_s = reinterpret_cast<int2 *>(P.state0 + (long long)s * P.state_stride);
     const int ncand = P.NJ * P.NK;
-    unsigned long long work_cells = 0;
-    unsigned work_tiles = 0;
-    bool flagged = false;       // this workgroup has set the start's "improved" bit in this launch
-    for (int c0 = g; c0 < ncand; c0 += 64 * G) {
-      const TileCand pick = tile_candidate(P, state_s, c0 + lane * G, ncand);
+    const long long nwg = (long long)gridDim.x, ntotal = (long long)ncand * P.nactive;
+    TileWork work;
+    for (long long t0 = blockIdx.x; t0 < ntotal; t0 += 64 * nwg) {
+      const TileCand pick = tile_candidate(P, t0 + lane * nwg, ncand);
       unsigned long long due_lanes = __ballot(pick.due);
       while (due_lanes) {
         const int src = __builtin_ctzll(due_lanes);
         due_lanes &= due_lanes - 1;
         const int tile = __builtin_amdgcn_readlane(pick.tile, src);
-        work_cells += (unsigned)__builtin_amdgcn_readlane((int)pick.cells, src);
-        work_tiles++;
+        const int act = __builtin_amdgcn_readlane(pick.a, src);
+        const int s = uni(P.active[act]);
+        tile_work_count(P, work, act, (unsigned)__builtin_amdgcn_readlane((int)pick.cells, src), lane);
         PROF_STAMP(t_top);
 
         const const_start_ptr sdp = (const_start_ptr)(P.starts + s);
@@ -442,12 +505,7 @@ tile_sweep_kernel(TileSweep P)
                 }
             }
             tile_stamp_neighbours(P, state, I, J, K, lane);
-            // (once per workgroup: an atomic per improved tile on the starts' few words holds
-            // every tile up - see tile_work_add)
-            if (!flagged) {
-                if (lane == 0) atomicOr(&P.changed[s], CHANGED_IMPROVED);
-                flagged = true;
-            }
+            tile_work_improved(work, act, lane);
         }
         // (the image is overwritten by the next tile's loads: every read of it has been
         // consumed; the stores are in flight and read registers only)
@@ -464,7 +522,7 @@ tile_sweep_kernel(TileSweep P)
 #endif
       }
     }
-    tile_work_add(P, s, work_cells, work_tiles, lane);
+    tile_work_flush(P, work);
 #ifdef TTSWEEP_TILE_PROFILE
     if (lane == 0 && prof_acc[4]) {
         for (int i = 0; i < 5; i++) atomicAdd(&g_tile_prof[i], prof_acc[i]);
@@ -601,24 +659,22 @@ tile_six_kernel(TileSweep P)
     unsigned long long prof_acc[5] = {};
 #endif
     PROF_STAMP(t_begin);
-    // (the start's volume and activity words from the launch arguments: no descriptor load)
-    const int G = uni(P.groups), g = uni((int)blockIdx.x % P.groups);
-    const int s = uni(P.active[blockIdx.x / P.groups]);
-    float *const T = uni_ptr(P.T0 + (long long)s * L.cells);
-    int2 *const state = uni_ptr(reinterpret_cast<int2 *>(P.state0 + (long long)s * P.state_stride));
     const int ncand = P.NJ * P.NK;
-    unsigned long long work_cells = 0;
-    unsigned work_tiles = 0;
-    bool flagged = false;
-    for (int c0 = g; c0 < ncand; c0 += 64 * G) {
-      const TileCand pick = tile_candidate(P, state, c0 + lane * G, ncand);
+    const long long nwg = (long long)gridDim.x, ntotal = (long long)ncand * P.nactive;
+    TileWork work;
+    for (long long t0 = blockIdx.x; t0 < ntotal; t0 += 64 * nwg) {
+      const TileCand pick = tile_candidate(P, t0 + lane * nwg, ncand);
       unsigned long long due_lanes = __ballot(pick.due);
       while (due_lanes) {
         const int src = __builtin_ctzll(due_lanes);
         due_lanes &= due_lanes - 1;
         const int tile = __builtin_amdgcn_readlane(pick.tile, src);
-        work_cells += (unsigned)__builtin_amdgcn_readlane((int)pick.cells, src);
-        work_tiles++;
+        const int act = __builtin_amdgcn_readlane(pick.a, src);
+        const int s = uni(P.active[act]);
+        tile_work_count(P, work, act, (unsigned)__builtin_amdgcn_readlane((int)pick.cells, src), lane);
+        // (the start's volume and activity words from the launch arguments: no descriptor load)
+        float *const T = uni_ptr(P.T0 + (long long)s * L.cells);
+        int2 *const state = uni_ptr(reinterpret_cast<int2 *>(P.state0 + (long long)s * P.state_stride));
         PROF_STAMP(t_top);
         const int K = tile % P.NK, J = (tile / P.NK) % P.NJ, I = tile / (P.NK * P.NJ);
 
@@ -688,10 +744,7 @@ tile_six_kernel(TileSweep P)
             tface[tile_face_index(L, 1, K, 1, 0, pa, pb)] = img[SIXC_T + row * TILE_Z];
             tface[tile_face_index(L, 1, K + 1, 0, 0, pa, pb)] = img[SIXC_T + row * TILE_Z + TILE_Z - 1];
             tile_stamp_neighbours(P, state, I, J, K, lane);
-            if (!flagged) {
-                if (lane == 0) atomicOr(&P.changed[s], CHANGED_IMPROVED);
-                flagged = true;
-            }
+            tile_work_improved(work, act, lane);
         }
 #ifdef TTSWEEP_TILE_PROFILE
         {
@@ -705,7 +758,7 @@ tile_six_kernel(TileSweep P)
 #endif
       }
     }
-    tile_work_add(P, s, work_cells, work_tiles, lane);
+    tile_work_flush(P, work);
 #ifdef TTSWEEP_TILE_PROFILE
     if (lane == 0 && prof_acc[4]) {
         for (int i = 0; i < 5; i++) atomicAdd(&g_tile_prof[i], prof_acc[i]);
@@ -772,10 +825,8 @@ hipError_t tile_sweep_wgs_per_cu(const TileSweep &P, int *wgs)
 hipError_t launch_tile_sweep(const TileSweep &P, hipStream_t st)
 {
     if (P.nactive <= 0) return hipSuccess;
-    if (!tile_sweep_ok(P) || P.groups < 1) return hipErrorInvalidValue;
-    const long long nblocks = (long long)P.groups * P.nactive;
-    if (nblocks > 0x7fffffffLL) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(tile_instance(P), dim3((unsigned)nblocks), dim3(64), tile_instance_lds(P), st, P);
+    if (!tile_sweep_ok(P) || P.nblocks < 1 || !P.wgwork || P.nstart < P.nactive) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(tile_instance(P), dim3((unsigned)P.nblocks), dim3(64), tile_instance_lds(P), st, P);
     return hipGetLastError();
 }
 
