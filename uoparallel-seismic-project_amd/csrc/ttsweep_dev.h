@@ -181,7 +181,8 @@ struct TileEntry {
 
 // Arguments of one launch of tile_sweep_kernel: the tiles of hyperplane D of a sweep with
 // ordering (sx, sy, sz), for every active start.  The grid is `nblocks` single-wavefront
-// workgroups; the candidates (active start, J', K') are dealt round-robin over them.
+// workgroups (a multiple of nxcd); the candidates ((J', K'), active start) are dealt over them
+// position by position (ttsweep_tile.hip: tile_candidate).
 struct TileSweep {
     DevLayout L;
     const float *v;
@@ -190,6 +191,8 @@ struct TileSweep {
     int *changed;           // "changed" words of this sweep, per start
     int nactive;
     int nblocks;            // workgroups of the launch
+    int nxcd;               // XCDs of the device (workgroup b is taken to run on XCD b % nxcd)
+    int wstride;            // workgroups per XCD that take candidates: <= nblocks / nxcd, coprime to nactive
     int nstart;             // starts of the solve (slots per workgroup in wgwork)
     unsigned long long *wgwork;     // [nblocks][nstart][2]: private work sums of the workgroups (relaxations, tiles)
     int NI, NJ, NK;         // tiles along a, b, c

@@ -42,7 +42,7 @@ static int launch_pass_strip(ttsweep_ctx *ctx, int nactive, int nstart, int *d_c
     const StripPlan &plan = ctx->plans[ctx->np - 1];
     HIPCHK(launch_plan_pass(ctx->L, ctx->d_starts, ctx->d_worklist, ctx->worklist_len, d_changed,
                             ctx->d_unitq, (int)ctx->unitq_cap, ctx->nlists, ctx->d_unitq_ctrl,
-                            plan, gate_r2(ctx), ctx->stream));
+                            plan, gate_r2(ctx), ctx->d_tile_flags, (long long)flag_words(ctx->L), ctx->stream));
     UnitPassTail tail;
     tail.active = ctx->d_active;
     tail.nactive = nactive;
@@ -97,6 +97,8 @@ static int prepare_tile_sweep(ttsweep_ctx *ctx)
     }
     // the workgroups' private work sums: [tile_blocks][nstart][2], zero between solves
     P.nblocks = ctx->tile_blocks;
+    P.nxcd = std::max(ctx->nlists, 1);
+    if (ctx->tile_blocks % P.nxcd) P.nxcd = 1;
     P.nstart = ctx->stats.nstart;
     const size_t need = (size_t)ctx->tile_blocks * (size_t)P.nstart * 2;
     if (need > ctx->tile_wgwork_cap) {
@@ -118,8 +120,14 @@ static int launch_pass_tile(ttsweep_ctx *ctx, int nactive, int *d_changed)
     TileSweep &P = ctx->tile_sweep;
     P.changed = d_changed;
     P.nactive = nactive;
-    // the resident grid (no more workgroups than candidates)
+    // the resident grid (no more workgroups than candidates; whole XCD rounds)
     P.nblocks = (int)std::min<long long>(ctx->tile_blocks, (long long)P.NJ * P.NK * nactive);
+    P.nblocks = std::max(P.nblocks / P.nxcd, 1) * P.nxcd;
+    // workgroups per XCD that take candidates: coprime to the number of active starts, so that
+    // one start's tiles at consecutive positions go to different workgroups (tile_candidate)
+    auto gcd = [](int a, int b) { while (b) { const int t = a % b; a = b; b = t; } return a; };
+    P.wstride = P.nblocks / P.nxcd;
+    while (P.wstride > 1 && gcd(P.wstride, nactive) != 1) P.wstride--;
     const int o = ctx->pass_index & 7;                  // the eight orderings in turn
     P.sx = (o & 1) ? -1 : 1;
     P.sy = (o & 2) ? -1 : 1;

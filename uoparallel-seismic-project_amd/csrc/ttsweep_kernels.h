@@ -58,7 +58,8 @@ size_t units_lds_bytes(const StripPlan &plan, int nb);
 int units_wgs_per_cu();     // persistent workgroups per CU the unit kernel is built for
 hipError_t launch_plan_pass(const DevLayout &L, const StartDesc *starts, const int2 *work,
                             long long nwork, int *changed, int4 *lists, int list_cap, int nlists,
-                            int *ctrl, const StripPlan &plan, float gate_r2, hipStream_t st);
+                            int *ctrl, const StripPlan &plan, float gate_r2, int *flags0, long long flags_stride,
+                            hipStream_t st);      // (flags0 + s * flags_stride = starts[s].tile_flags)
 hipError_t launch_sweep_units(const DevLayout &L, const float *v, const StartDesc *starts,
                               const int4 *lists, int list_cap, int nlists, int *ctrl, int nblocks,
                               int *changed, const StripItem *items, const StripPlan &plan,

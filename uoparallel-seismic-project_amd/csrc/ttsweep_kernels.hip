@@ -777,7 +777,7 @@ __global__ void __launch_bounds__(256)
 plan_pass_kernel(DevLayout L, const StartDesc *__restrict__ starts, const int2 *__restrict__ work,
                  long long nwork, int *__restrict__ changed, int4 *__restrict__ lists, int list_cap,
                  int *__restrict__ ctrl, int nlists, int ra, int np, int btiles, int cstrips,
-                 float gate_r2, PlaneCounts pc)
+                 float gate_r2, PlaneCounts pc, int *__restrict__ flags0, long long flags_stride)
 {
     // wave W handles 64 consecutive entries of ONE XCD's sub-list, so that a wave-level
     // compaction keeps the work-list order (nearest to the start first) inside a queue
@@ -794,16 +794,22 @@ plan_pass_kernel(DevLayout L, const StartDesc *__restrict__ starts, const int2 *
         unit = item.y;
     }
     if (unit >= 0) {
+        // staged planes that changed since this unit last relaxed against them, and plane
+        // bits it was held back with (push_improved, seed_pend_kernel); most units have none
+        // and leave after this one word
+        const int nflag = L.n[0] * btiles * cstrips;
+        int *const tile_flags = flags0 + (long long)s * flags_stride;       // (= starts[s].tile_flags)
+        unsigned *__restrict__ pend = reinterpret_cast<unsigned *>(tile_flags + 2 * nflag);
+        planes = pend[unit];
+    }
+    if (planes != 0) {
         const StartDesc sd = starts[s];
         const int nflag = L.n[0] * btiles * cstrips;
+        unsigned *__restrict__ pend = reinterpret_cast<unsigned *>(sd.tile_flags + 2 * nflag);
         int u = unit;
         const int cs = u % cstrips;  u /= cstrips;
         const int bt = u % btiles;   u /= btiles;
         const int a0 = np * u;                  // first own plane
-        // staged planes that changed since this unit last relaxed against them, and plane
-        // bits it was held back with (push_improved, seed_pend_kernel)
-        unsigned *__restrict__ pend = reinterpret_cast<unsigned *>(sd.tile_flags + 2 * nflag);
-        planes = pend[unit];
         // distance gate
         const int b0 = bt * STRIP_TB, cb0 = cs * STRIP_K;
         const int tb_eff = min(STRIP_TB, L.n[1]);
@@ -1319,7 +1325,8 @@ size_t units_lds_bytes(const StripPlan &plan, int nb)
 
 hipError_t launch_plan_pass(const DevLayout &L, const StartDesc *starts, const int2 *work,
                             long long nwork, int *changed, int4 *lists, int list_cap, int nlists,
-                            int *ctrl, const StripPlan &plan, float gate_r2, hipStream_t st)
+                            int *ctrl, const StripPlan &plan, float gate_r2, int *flags0, long long flags_stride,
+                            hipStream_t st)
 {
     if (nwork <= 0) return hipSuccess;
     if (nlists < 1 || nlists > UNITQ_LISTS) return hipErrorInvalidValue;
@@ -1334,7 +1341,7 @@ hipError_t launch_plan_pass(const DevLayout &L, const StartDesc *starts, const i
         for (int j = 0; j < STRIP_PLANES; j++) pc.n[p][j] = p < plan.nstaged ? plan.nent[p][j] : 0;
     hipLaunchKernelGGL(plan_pass_kernel, dim3((unsigned)nblocks), dim3(256), 0, st, L, starts, work,
                        nwork, changed, lists, list_cap, ctrl, nlists, plan.ra, plan.np, btiles, strip_cstrips(L),
-                       gate_r2, pc);
+                       gate_r2, pc, flags0, flags_stride);
     return hipGetLastError();
 }
 

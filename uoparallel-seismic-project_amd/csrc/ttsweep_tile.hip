@@ -152,16 +152,29 @@ __device__ __forceinline__ T *uni_ptr(T *p)
 // A launch relaxes the due tiles of ONE hyperplane D for every active start; there is no
 // separate planning kernel and no list (round 2 had both: a planner kernel and a second kernel
 // boundary in front of every one of the ~5700 launches of a solve).  The candidates of a launch
-// are the pairs (active start, (J', K')), NJ * NK * nactive of them; workgroup b owns candidates
-// b, b + grid, b + 2 grid, ... - round-robin over ALL starts, so that the load of a workgroup is
-// the launch's average whatever start the due tiles belong to and wherever they cluster -,
-// evaluates up to 64 of them at a time, one per lane (the tile's two stamps, one 8-byte load),
-// and then relaxes the due ones in turn.  A tile is due when one of its 27 neighbours (itself
-// included) improved in or after the epoch it was last relaxed in (they stamp its y word when
-// they do: tile_stamp_neighbours).  Tiles of the same hyperplane may improve while a workgroup
-// is still evaluating: it then either sees the new stamp (and relaxes a tile that would have
-// been due in the next sweep anyway) or does not (the stamp is >= the tile's own, so the tile is
-// due in a later launch): nothing is ever skipped for good.
+// are the pairs (tile position (J', K'), active start), NJ * NK * nactive of them, and they are
+// dealt so that
+//   * the tiles of ALL starts at one position are relaxed at the same time on the same XCD - by
+//     nactive neighbouring workgroups of the XCD that position belongs to ((J' + K') % XCDs;
+//     workgroup b runs on XCD b % XCDs: observed dispatch order, a speed matter only): the
+//     starts share the velocity volume, so its tile image comes from HBM once and from that
+//     XCD's L2 for the other starts (dealt start by start, the same image was wanted at nactive
+//     different times of a launch whose working set is ten times the L2s: measured 319 ms
+//     against 247 ms per solve on 1024x1024x512 x 14 starts);
+//   * every workgroup's share is the launch's average whatever start the due tiles belong to
+//     and wherever they cluster: workgroup j of an XCD owns candidates j, j + W, j + 2 W, ...
+//     of that XCD's (position, start) sequence, with W = the largest number of workgroups per
+//     XCD that is COPRIME to the number of active starts - the tiles of one start at consecutive
+//     positions, nactive apart in the sequence, then go to W different workgroups before one
+//     gets a second (with W = 192 and 14 starts they went to 96 of them: the early sweeps, in
+//     which every start's due tiles are one compact cluster, took 2.4 times as long).
+// A workgroup evaluates up to 64 of its candidates at a time, one per lane (the tile's two
+// stamps, one 8-byte load), and then relaxes the due ones in turn.  A tile is due when one of
+// its 27 neighbours (itself included) improved in or after the epoch it was last relaxed in
+// (they stamp its y word when they do: tile_stamp_neighbours).  Tiles of the same hyperplane
+// may improve while a workgroup is still evaluating: it then either sees the new stamp (and
+// relaxes a tile that would have been due in the next sweep anyway) or does not (the stamp is
+// >= the tile's own, so the tile is due in a later launch): nothing is ever skipped for good.
 struct TileCand {
     int a;              // index into the active list
     int tile;           // (I * NJ + J) * NK + K
@@ -169,14 +182,23 @@ struct TileCand {
     bool due;
 };
 
-__device__ __forceinline__ TileCand tile_candidate(const TileSweep &P, long long t, int ncand)
+// q: index into this XCD's (position, start) sequence; x: the XCD.  Position (J', K') belongs to
+// XCD (J' + K') % nxcd - not to (J' NK + K') % nxcd = K' % nxcd: the first sweeps of a solve
+// whose starts lie in the top layer only have due tiles with one K', and all of them landed on
+// ONE XCD (measured: those sweeps took twice as long).  The positions of XCD x in sequence:
+// J' = 0 .. NJ - 1, and for each J' the K' = (x - J') mod nxcd + nxcd m, m = 0 .. M - 1.
+__device__ __forceinline__ TileCand tile_candidate(const TileSweep &P, long long q, int x, int ncand)
 {
     TileCand r{0, 0, 0u, false};
-    if (t >= (long long)ncand * P.nactive) return r;
-    r.a = (int)(t / ncand);
-    const int c = (int)(t - (long long)r.a * ncand);
+    (void)ncand;
+    const int M = (P.NK + P.nxcd - 1) / P.nxcd;
+    const long long pos = q / P.nactive;
+    const int Jp = (int)(pos / M), m = (int)(pos - (long long)Jp * M);
+    if (Jp >= P.NJ) return r;
+    const int Kp = ((x - Jp) % P.nxcd + P.nxcd) % P.nxcd + P.nxcd * m;
+    if (Kp >= P.NK) return r;
+    r.a = (int)(q - pos * P.nactive);
     int2 *__restrict__ state = reinterpret_cast<int2 *>(P.state0 + (long long)P.active[r.a] * P.state_stride);
-    const int Kp = c % P.NK, Jp = c / P.NK;
     const int Ip = P.D - Jp - Kp;
     if (Ip < 0 || Ip >= P.NI) return r;
     const int I = P.sx > 0 ? Ip : P.NI - 1 - Ip;
@@ -347,10 +369,12 @@ tile_sweep_kernel(TileSweep P)
     // (everything that selects the tile is kept in scalar registers: the start descriptor then
     // comes through the scalar cache and the buffer descriptors need no waterfall loop)
     const int ncand = P.NJ * P.NK;
-    const long long nwg = (long long)gridDim.x, ntotal = (long long)ncand * P.nactive;
+    const int xcd = uni((int)blockIdx.x % P.nxcd);
+    const long long W = P.wstride;              // workgroups of an XCD that take candidates (coprime to nactive)
+    const long long nseq = (long long)P.NJ * ((P.NK + P.nxcd - 1) / P.nxcd) * P.nactive;   // candidates of an XCD
     TileWork work;
-    for (long long t0 = blockIdx.x; t0 < ntotal; t0 += 64 * nwg) {
-      const TileCand pick = tile_candidate(P, t0 + lane * nwg, ncand);
+    for (long long q0 = blockIdx.x / P.nxcd; q0 < nseq && (long long)(blockIdx.x / P.nxcd) < W; q0 += 64 * W) {
+      const TileCand pick = tile_candidate(P, q0 + lane * W, xcd, ncand);
       unsigned long long due_lanes = __ballot(pick.due);
       while (due_lanes) {
         const int src = __builtin_ctzll(due_lanes);
@@ -660,10 +684,12 @@ tile_six_kernel(TileSweep P)
 #endif
     PROF_STAMP(t_begin);
     const int ncand = P.NJ * P.NK;
-    const long long nwg = (long long)gridDim.x, ntotal = (long long)ncand * P.nactive;
+    const int xcd = uni((int)blockIdx.x % P.nxcd);
+    const long long W = P.wstride;              // workgroups of an XCD that take candidates (coprime to nactive)
+    const long long nseq = (long long)P.NJ * ((P.NK + P.nxcd - 1) / P.nxcd) * P.nactive;   // candidates of an XCD
     TileWork work;
-    for (long long t0 = blockIdx.x; t0 < ntotal; t0 += 64 * nwg) {
-      const TileCand pick = tile_candidate(P, t0 + lane * nwg, ncand);
+    for (long long q0 = blockIdx.x / P.nxcd; q0 < nseq && (long long)(blockIdx.x / P.nxcd) < W; q0 += 64 * W) {
+      const TileCand pick = tile_candidate(P, q0 + lane * W, xcd, ncand);
       unsigned long long due_lanes = __ballot(pick.due);
       while (due_lanes) {
         const int src = __builtin_ctzll(due_lanes);
@@ -825,7 +851,9 @@ hipError_t tile_sweep_wgs_per_cu(const TileSweep &P, int *wgs)
 hipError_t launch_tile_sweep(const TileSweep &P, hipStream_t st)
 {
     if (P.nactive <= 0) return hipSuccess;
-    if (!tile_sweep_ok(P) || P.nblocks < 1 || !P.wgwork || P.nstart < P.nactive) return hipErrorInvalidValue;
+    if (!tile_sweep_ok(P) || P.nxcd < 1 || P.nblocks < P.nxcd || P.nblocks % P.nxcd || !P.wgwork || P.nstart < P.nactive
+        || P.wstride < 1 || P.wstride > P.nblocks / P.nxcd)
+        return hipErrorInvalidValue;
     hipLaunchKernelGGL(tile_instance(P), dim3((unsigned)P.nblocks), dim3(64), tile_instance_lds(P), st, P);
     return hipGetLastError();
 }
