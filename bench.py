@@ -196,20 +196,27 @@ def host_program_end_to_end(P, shape, star, starts, v_host):
         with open(sfile, "w") as f:
             f.write(f"{len(starts)}\n" + "".join(f"{i} {j} {k}\n" for i, j, k in starts))
         env = dict(os.environ, TTSWEEP_NO_OUTPUT="1")
-        t0 = time.perf_counter()
-        r = subprocess.run([exe, vfile, P.inputs.star_path(star), sfile], capture_output=True, text=True,
-                           timeout=600, env=env, cwd=d)
-        wall = time.perf_counter() - t0
-        if r.returncode != 0:
-            return None
-        loop = [ln for ln in r.stdout.splitlines() if ln.startswith("ttsweep: sweep loop")]
-        dev = [ln for ln in r.stdout.splitlines() if "ms on device" in ln]
-        return {"process_wall_seconds": round(wall, 3),
-                "sweep_loop_wall_seconds": float(loop[-1].split()[3]) if loop else None,
-                "device_ms": float(dev[0].split()[-4]) if dev else None,
-                "what": "host/sweep-tt-multistart <vbox> <star> <starts> with TTSWEEP_NO_OUTPUT=1: process start, "
-                        "VBOX load, context creation, pinned host<->device transfers of every box, solve, "
-                        "confirming second driver pass"}
+        runs = []
+        for _ in range(2):      # (the first run of a fresh box pages the system HIP runtime in from the image)
+            t0 = time.perf_counter()
+            r = subprocess.run([exe, vfile, P.inputs.star_path(star), sfile], capture_output=True, text=True,
+                               timeout=600, env=env, cwd=d)
+            wall = time.perf_counter() - t0
+            if r.returncode != 0:
+                return None
+            loop = [ln for ln in r.stdout.splitlines() if ln.startswith("ttsweep: sweep loop")]
+            dev = [ln for ln in r.stdout.splitlines() if "ms on device" in ln]
+            runs.append({"process_wall_seconds": round(wall, 3),
+                         "sweep_loop_wall_seconds": float(loop[-1].split()[3]) if loop else None,
+                         "device_ms": float(dev[0].split()[-4]) if dev else None})
+        out = dict(runs[1])
+        out["first_run_on_this_box"] = runs[0]
+        out["what"] = ("host/sweep-tt-multistart <vbox> <star> <starts> with TTSWEEP_NO_OUTPUT=1: process start, VBOX load, "
+                       "context creation (its HIP runtime initialises on a thread of its own from process start), pinned "
+                       "host<->device transfers of every box, solve, confirming second driver pass (answered from box "
+                       "digests).  Run twice: the figures are the second run's; the first run of a fresh box also pages "
+                       "the system libamdhip64 / HSA runtime in from the container image (first_run_on_this_box)")
+        return out
     except Exception:
         return None
     finally:

@@ -416,6 +416,9 @@ def test_512_grid_properties(P):
     assert np.isfinite(tt).all() and tt[tuple(starts[0])] == 0 and (tt >= 0).all()
     v = v_dev.cpu().numpy()
     assert sampled_open_edges(v, tt, offs, starts[0], 20000, 2) == 0
+    # every cell once more, by code that shares nothing with the library (plain PyTorch)
+    from torch_checker import fixed_point_counts
+    assert fixed_point_counts(v_dev, torch.from_numpy(tt).to(dev), fs, starts[0]) == (0, 0, 0)
 
 
 SHELL26 = np.array([[a, b, c] for a in (-1, 0, 1) for b in (-1, 0, 1) for c in (-1, 0, 1) if (a, b, c) != (0, 0, 0)]
@@ -509,17 +512,18 @@ def test_tile_kernel_512_grid_matches_cell_kernel(P):
 
 def test_tile_kernel_1024_grid_six_star(P):
     """BASELINE.json config 5's "HBM-roofline run": the 6-neighbour star on 1024x1024x512
-    (volumes of 2.2 GB), two starts in one batch, pinned by the device validator (every
-    cell) and by idempotence."""
-    st = _batched_config_check(P, (1024, 1024, 512), 2, star="six")
+    (volumes of 2.2 GB), two starts in one batch, pinned by the device validator and by the
+    plain-PyTorch checker (every cell, both) and by idempotence."""
+    st = _batched_config_check(P, (1024, 1024, 512), 2, star="six", torch_checked=2)
     assert st["kernel_variant"] == 3
 
 
-def _batched_config_check(P, shape, nstart, star="818"):
+def _batched_config_check(P, shape, nstart, star="818", torch_checked=0):
     """One batched device-resident solve of `nstart` scaled start-111 points on a synthetic
     grid; every box is then pinned by the device validator (nothing can improve, nothing is
-    too small, nothing left at INFINITY), and a second solve of the converged boxes must
-    report "no change" and leave every bit alone."""
+    too small, nothing left at INFINITY) - the first `torch_checked` boxes also by the
+    plain-PyTorch checker, which shares no code with the library -, and a second solve of the
+    converged boxes must report "no change" and leave every bit alone."""
     import torch
     dev = torch.device("cuda:0")
     v_dev = P.inputs.velocity_model_device(*shape, 20160507, dev)
@@ -535,6 +539,9 @@ def _batched_config_check(P, shape, nstart, star="818"):
         for s in range(nstart):
             assert sol.validate_device(starts[s], tt[s]) == (0, 0, 0), f"start {s} {starts[s]}"
             assert float(tt[s][tuple(starts[s])]) == 0.0
+        from torch_checker import fixed_point_counts
+        for s in range(min(torch_checked, nstart)):
+            assert fixed_point_counts(v_dev, tt[s], fs, starts[s]) == (0, 0, 0), f"start {s} {starts[s]} (torch)"
         assert bool(torch.isfinite(tt).all()) and float(tt.min()) == 0.0
         digest = [int(tt[s].view(torch.int32).to(torch.int64).sum().item()) for s in range(nstart)]
         assert sol.solve_device(starts, tt, init=False) == 0
@@ -545,7 +552,7 @@ def _batched_config_check(P, shape, nstart, star="818"):
 def test_config_512_grid_eight_starts(P):
     """BASELINE.json config 4 at its stated batch: 512x512x256, 8 starts, 818-FS, one
     batched solve (8 travel-time volumes resident, work list of 8 x the unit grid)."""
-    _batched_config_check(P, (512, 512, 256), 8)
+    _batched_config_check(P, (512, 512, 256), 8, torch_checked=2)
 
 
 def test_config_1024_grid_one_gpu_share(P):
@@ -556,10 +563,11 @@ def test_config_1024_grid_one_gpu_share(P):
 
 def test_volume_above_2_gib(P):
     """818-FS on 1024x1024x512 (padded volumes of 2.3 GB: byte offsets beyond 2^31 inside one
-    volume).  No second implementation is fast enough here, so the box is pinned by the
-    device validator alone: nothing can improve and nothing is too small, i.e. it is the
-    fixed point; plus the size-independent properties (start 0, finite, non-negative, a
-    second solve changes nothing)."""
+    volume).  No second relaxation is fast enough here, so the box is pinned by two independent
+    fixed-point checks over every cell and offset - the library's device validator and a
+    plain-PyTorch restatement of the reference's store conditions -: nothing can improve and
+    nothing is too small, i.e. it is the fixed point; plus the size-independent properties
+    (start 0, finite, non-negative, a second solve changes nothing)."""
     import torch
     shape = (1024, 1024, 512)
     dev = torch.device("cuda:0")
@@ -572,6 +580,10 @@ def test_volume_above_2_gib(P):
         assert sol.solve_device(starts, tt, init=True) == 1
         assert sol.stats()["kernel_variant"] == 2
         assert sol.validate_device(starts[0], tt[0]) == (0, 0, 0)
+        # ... and by the plain-PyTorch restatement of the reference's store conditions (every cell,
+        # every offset; tests/torch_checker.py, pinned against the oracle on the CPU tier)
+        from torch_checker import fixed_point_counts
+        assert fixed_point_counts(v_dev, tt[0], fs, starts[0]) == (0, 0, 0)
         assert float(tt[0][tuple(starts[0])]) == 0.0
         assert bool(torch.isfinite(tt).all()) and float(tt.min()) == 0.0
         before = tt.clone()

@@ -120,3 +120,33 @@ def test_full_size_3fs_digest(oracle):
     fs = oracle.make_star(oracle.read_triples(P.inputs.star_path("3")))
     tt, sweeps, _ = oracle.converge(v, fs, (120, 120, 50), order=1)
     assert hashlib.sha256(tt.tobytes()).hexdigest() == want["sha256"]
+
+
+def test_torch_checker_counts_what_the_oracle_validator_counts(oracle, pkg):
+    """tests/torch_checker.py (plain PyTorch, used on the GPU tier for the grids no CPU run
+    reaches) against the oracle's validator on the reference's own states: the converged box
+    and the states after one and two reference passes, symmetric and non-symmetric stars."""
+    import json
+    import os
+
+    import torch
+    from conftest import GOLDEN
+    from torch_checker import fixed_point_counts
+    z = np.load(os.path.join(GOLDEN, "g24.npz"))
+    meta = json.loads(bytes(z["meta"]).decode())
+    v = z["v"]
+    for sname in ("818", "nonsym", "3"):
+        if f"pass_{sname}" not in meta:
+            continue
+        offs, start = z[f"star_{sname}"], meta[f"pass_{sname}"]["start"]
+        ofs, fs = oracle.make_star(offs), pkg.inputs.make_fs(offs)
+        conv, _, _ = oracle.converge(v, ofs, start)
+        for tt in (conv, z[f"pass1_{sname}"], z[f"pass2_{sname}"]):
+            want = oracle.validate(v, tt, ofs, start)
+            got = fixed_point_counts(torch.from_numpy(v), torch.from_numpy(np.ascontiguousarray(tt)), fs, start)
+            assert got[:2] == want and got[2] == 0, (sname, got, want)
+        bad = conv.copy()
+        far = tuple(0 if 2 * s >= n else n - 1 for s, n in zip(start, conv.shape))
+        bad[far] = np.float32(0.5) * bad[far]
+        opened, _, unsupported = fixed_point_counts(torch.from_numpy(v), torch.from_numpy(bad), fs, start)
+        assert opened > 0 and unsupported >= 1
