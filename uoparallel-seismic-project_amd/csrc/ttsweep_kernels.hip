@@ -6,7 +6,10 @@
 // with three separately rounded float operations.  The file is compiled with
 // -ffp-contract=off so the multiply and the add are never fused into an FMA.
 // Halving is exact, so folding "/ 2.0" into h on the host leaves every bit
-// unchanged (fl(d*s)/2 == fl((d/2)*s) for normal floats).
+// unchanged (fl(d*s)/2 == fl((d/2)*s)) - for NORMAL products d*s: a denormal product
+// is rounded at denormal precision first and halving it rounds again.  The boundary
+// therefore refuses velocity volumes in which a product could be denormal
+// (ttsweep_set_velocity*, count_bad_velocity_kernel).
 #include "ttsweep_kernels.h"
 #include <cstdio>
 
