@@ -532,12 +532,21 @@ int ttsweep_solve(ttsweep_ctx *ctx, int nstart, const ttsweep_start *starts,
             fprintf(stderr, "ttsweep_solve: %s %.1f ms\n", what, std::chrono::duration<double, std::milli>(now - t_phase).count());
             t_phase = now;
         };
-        for (int s = 0; s < n; s++) {
-            ptrs[s] = stage + (size_t)s * cells;
-            if (hipHostRegister(tt_host[first + s], cells * sizeof(float), hipHostRegisterDefault) == hipSuccess)
-                pinned[s] = 1;
-            else
-                (void)hipGetLastError();
+        for (int s = 0; s < n; s++) ptrs[s] = stage + (size_t)s * cells;
+        {   // (page-locking is host work per page: a few threads side by side)
+            const int nthreads = std::max(1, std::min({n, 4, (int)std::thread::hardware_concurrency()}));
+            std::vector<std::thread> pool;
+            for (int t = 0; t < nthreads; t++)
+                pool.emplace_back([&, t]() {
+                    if (hipSetDevice(ctx->device) != hipSuccess) return;
+                    for (int s = t; s < n; s += nthreads) {
+                        if (hipHostRegister(tt_host[first + s], cells * sizeof(float), hipHostRegisterDefault) == hipSuccess)
+                            pinned[s] = 1;
+                        else
+                            (void)hipGetLastError();
+                    }
+                });
+            for (auto &th : pool) th.join();
         }
         lap("pin the caller's boxes");
         for (int s = 0; s < n && rc == 0; s++) {
@@ -548,21 +557,49 @@ int ttsweep_solve(ttsweep_ctx *ctx, int nstart, const ttsweep_start *starts,
         lap("upload");
         if (rc == 0) rc = ttsweep_solve_device(ctx, n, starts + first, ptrs.data(), 0);
         lap("solve");
+        // what the caller will hold afterwards: the fixed point of every start - digested box by
+        // box as the downloads complete (an event per box, a few host threads)
+        std::vector<uint64_t> dig(n, 0);
+        std::vector<hipEvent_t> landed;
         if (rc > 0) {       // (rc == 0: nothing was stored, the caller's boxes are the result already)
             for (int s = 0; s < n; s++) {
                 hipError_t e = hipMemcpyAsync(tt_host[first + s], ptrs[s], cells * sizeof(float),
                                               hipMemcpyDeviceToHost, ctx->stream);
+                hipEvent_t ev = nullptr;
+                if (e == hipSuccess) e = hipEventCreateWithFlags(&ev, hipEventDisableTiming);
+                if (e == hipSuccess) e = hipEventRecord(ev, ctx->stream);
+                if (ev) landed.push_back(ev);
                 if (e != hipSuccess) {
                     rc = set_error("travel-time download failed: %s", hipGetErrorString(e));
                     break;
                 }
             }
         }
+        if (rc >= 0) {
+            const bool by_event = (int)landed.size() == n;
+            if (!by_event) (void)hipStreamSynchronize(ctx->stream);
+            const int nthreads = std::max(1, std::min({n, 4, (int)std::thread::hardware_concurrency()}));
+            std::vector<std::thread> pool;
+            for (int t = 0; t < nthreads; t++)
+                pool.emplace_back([&, t]() {
+                    if (hipSetDevice(ctx->device) != hipSuccess) return;
+                    for (int s = t; s < n; s += nthreads) {
+                        if (by_event && hipEventSynchronize(landed[s]) != hipSuccess) continue;
+                        dig[s] = box_digest(tt_host[first + s], cells);
+                    }
+                });
+            for (auto &th : pool) th.join();
+        }
         {
             hipError_t e = hipStreamSynchronize(ctx->stream);
             if (e != hipSuccess && rc >= 0) rc = set_error("travel-time transfer failed: %s", hipGetErrorString(e));
         }
-        lap("download");
+        for (hipEvent_t ev : landed) (void)hipEventDestroy(ev);
+        lap("download + digests");
+        if (rc >= 0) {
+            if (ctx->solved.size() + (size_t)n > 65536) ctx->solved.clear();       // (bounded memory)
+            for (int s = 0; s < n; s++) ctx->solved[tt_host[first + s]] = ttsweep_ctx::SolvedBox{starts[first + s], dig[s]};
+        }
         for (int s = 0; s < n; s++)
             if (pinned[s]) (void)hipHostUnregister(tt_host[first + s]);
         lap("unpin");
@@ -582,11 +619,6 @@ int ttsweep_solve(ttsweep_ctx *ctx, int nstart, const ttsweep_start *starts,
         total.kernel_variant = b.kernel_variant;
     }
     ctx->stats = total;
-    {   // what the caller now holds: the fixed point of every start
-        const std::vector<uint64_t> dig = box_digests(tt_host, nstart, cells);
-        if (ctx->solved.size() + (size_t)nstart > 65536) ctx->solved.clear();       // (bounded memory)
-        for (int s = 0; s < nstart; s++) ctx->solved[tt_host[s]] = ttsweep_ctx::SolvedBox{starts[s], dig[s]};
-    }
     return any;
 }
 
