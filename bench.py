@@ -198,6 +198,9 @@ def host_program_end_to_end(P, shape, star, starts, v_host):
         env = dict(os.environ, TTSWEEP_NO_OUTPUT="1")
         runs = []
         for _ in range(2):      # (the first run of a fresh box pages the system HIP runtime in from the image)
+            time.sleep(1.5)     # (the driver tears the previous GPU process down asynchronously: a process that
+                                #  starts right behind another one's exit waits for that inside its own HIP
+                                #  initialisation - 0.1-0.25 s that belong to the other process)
             t0 = time.perf_counter()
             r = subprocess.run([exe, vfile, P.inputs.star_path(star), sfile], capture_output=True, text=True,
                                timeout=600, env=env, cwd=d)
@@ -214,8 +217,10 @@ def host_program_end_to_end(P, shape, star, starts, v_host):
         out["what"] = ("host/sweep-tt-multistart <vbox> <star> <starts> with TTSWEEP_NO_OUTPUT=1: process start, VBOX load, "
                        "context creation (its HIP runtime initialises on a thread of its own from process start), pinned "
                        "host<->device transfers of every box, solve, confirming second driver pass (answered from box "
-                       "digests).  Run twice: the figures are the second run's; the first run of a fresh box also pages "
-                       "the system libamdhip64 / HSA runtime in from the container image (first_run_on_this_box)")
+                       "digests).  Run twice, each 1.5 s after the previous GPU process has exited (its teardown would "
+                       "otherwise be waited for inside this one's HIP initialisation): the figures are the second "
+                       "run's; the first run of a fresh box also pages the system libamdhip64 / HSA runtime in from "
+                       "the container image (first_run_on_this_box)")
         return out
     except Exception:
         return None
