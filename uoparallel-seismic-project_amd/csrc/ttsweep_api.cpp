@@ -186,6 +186,8 @@ void ttsweep_destroy(ttsweep_ctx *ctx)
     (void)hipFree(ctx->d_unitq_ctrl);
     (void)hipFree(ctx->d_work);
     (void)hipFree(ctx->d_tile_wgwork);
+    (void)hipFree(ctx->d_tile_dmin);
+    if (ctx->h_tile_dmin) (void)hipHostFree(ctx->h_tile_dmin);
     (void)hipFree(ctx->d_vface);
     (void)hipFree(ctx->d_tface);
     if (ctx->h_work) (void)hipHostFree(ctx->h_work);

@@ -104,6 +104,7 @@ struct ttsweep_ctx {
     ttsweep::TileSweep tile_sweep{};        // launch arguments of the solve in progress
     unsigned long long *d_tile_wgwork = nullptr;    // private work sums of the sweep kernel's workgroups
     size_t tile_wgwork_cap = 0;
+    int *d_tile_dmin = nullptr, *h_tile_dmin = nullptr;    // first hyperplane with a due tile, per sweep parity (device / pinned)
     int *d_tile_flags = nullptr;            // capacity_starts x activity words (flag_words)
     unsigned long long *d_work = nullptr;   // capacity_starts
     unsigned long long *h_work = nullptr;   // pinned

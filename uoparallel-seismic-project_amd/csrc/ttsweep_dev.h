@@ -198,6 +198,9 @@ struct TileSweep {
     int NI, NJ, NK;         // tiles along a, b, c
     int R;                  // max |da|, |db| (halo of the staged image along a and b)
     int sx, sy, sz;         // sweep ordering, +1 / -1 per axis
+    int nsx, nsy, nsz;      // ordering of the NEXT sweep
+    int *dmin_next;         // first hyperplane of the next sweep that can hold a due tile (atomicMin; the host
+                            // sets it to a large value before a sweep and starts the next sweep there)
     int D;                  // hyperplane: tiles with I' + J' + K' == D (coordinates in sweep direction)
     int epoch;              // launch number within the solve (>= 2)
     int nent;               // pull entries in use; ent[nent..] are no-ops (h = 0 onto the cell itself)

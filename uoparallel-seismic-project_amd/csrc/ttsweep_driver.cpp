@@ -110,6 +110,9 @@ static int prepare_tile_sweep(ttsweep_ctx *ctx)
     }
     HIPCHK(hipMemsetAsync(ctx->d_tile_wgwork, 0, need * sizeof(unsigned long long), ctx->stream));
     P.wgwork = ctx->d_tile_wgwork;
+    if (!ctx->d_tile_dmin) HIPCHK(hipMalloc((void **)&ctx->d_tile_dmin, 2 * sizeof(int)));
+    if (!ctx->h_tile_dmin) HIPCHK(hipHostMalloc((void **)&ctx->h_tile_dmin, 2 * sizeof(int)));
+    ctx->h_tile_dmin[0] = ctx->h_tile_dmin[1] = 0;
     return 0;
 }
 
@@ -128,17 +131,30 @@ static int launch_pass_tile(ttsweep_ctx *ctx, int nactive, int *d_changed)
     auto gcd = [](int a, int b) { while (b) { const int t = a % b; a = b; b = t; } return a; };
     P.wstride = P.nblocks / P.nxcd;
     while (P.wstride > 1 && gcd(P.wstride, nactive) != 1) P.wstride--;
-    const int o = ctx->pass_index & 7;                  // the eight orderings in turn
+    const int o = ctx->pass_index & 7, on = (ctx->pass_index + 1) & 7;     // the eight orderings in turn
     P.sx = (o & 1) ? -1 : 1;
     P.sy = (o & 2) ? -1 : 1;
     P.sz = (o & 4) ? -1 : 1;
+    P.nsx = (on & 1) ? -1 : 1;
+    P.nsy = (on & 2) ? -1 : 1;
+    P.nsz = (on & 4) ? -1 : 1;
+    // Hyperplanes in front of the first one that can hold a due tile are not launched: the
+    // previous sweep recorded, for THIS ordering, the earliest hyperplane next to a tile it
+    // improved (tile_next_plane; its word is on the host: TILE sweeps are enqueued one at a
+    // time, each after the previous one's words have arrived).  The first sweep of a solve
+    // starts at 0; a sweep that finds the word untouched has nothing to do at all.
     const int nsteps = P.NI + P.NJ + P.NK - 2;
-    for (int D = 0; D < nsteps; D++) {
+    const int slot = ctx->pass_index & 1;
+    const int first = ctx->pass_index == 0 ? 0 : std::min(ctx->h_tile_dmin[slot ^ 1], nsteps);
+    P.dmin_next = ctx->d_tile_dmin + slot;
+    HIPCHK(hipMemsetAsync(P.dmin_next, 0x7f, sizeof(int), ctx->stream));
+    for (int D = first; D < nsteps; D++) {
         P.D = D;
         P.epoch = ++ctx->tile_epoch;
         HIPCHK(launch_tile_sweep(P, ctx->stream));
     }
-    ctx->stats.launches += nsteps - 1;
+    HIPCHK(hipMemcpyAsync(ctx->h_tile_dmin + slot, P.dmin_next, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    ctx->stats.launches += nsteps - first - 1;
     return 0;
 }
 
@@ -249,10 +265,13 @@ int solve_device_body(ttsweep_ctx *ctx, int nstart, const ttsweep_start *starts,
     unsigned long long trace_prev = 0, trace_prev_un = 0;
     std::vector<int> snapshot[PASS_SLOTS];      // active starts of each pass in flight
     int nactive = nstart, launched = 0, processed = 0;
+    // (TILE: a sweep is milliseconds long and the host decides where the next one starts from
+    // what this one recorded, so sweeps are enqueued one at a time; STRIP / CELL: one ahead)
+    const int depth = ctx->kernel == TTSWEEP_KERNEL_TILE ? 1 : 2;
     bool anychange_ever = false;
     auto t_pass = std::chrono::steady_clock::now();
     while (processed < launched || nactive > 0) {
-        if (nactive > 0 && launched - processed < 2) {          // enqueue the next pass
+        if (nactive > 0 && launched - processed < depth) {      // enqueue the next pass
             const int slot = launched % PASS_SLOTS;
             int *dch = ctx->d_changed + (size_t)slot * nstart;
             int *hch_slot = ctx->h_changed + (size_t)slot * nstart;
@@ -272,7 +291,7 @@ int solve_device_body(ttsweep_ctx *ctx, int nstart, const ttsweep_start *starts,
             HIPCHK(hipEventRecord(ctx->ev_flags[slot], ctx->stream));
             snapshot[slot].assign(ctx->h_active, ctx->h_active + nactive);
             launched++;
-            if (launched - processed < 2 && nactive > 0 && launched == 1) continue;   // prime the pipeline
+            if (launched - processed < depth && nactive > 0 && launched == 1) continue;   // prime the pipeline
         }
         // examine the oldest pass in flight
         const int slot = processed % PASS_SLOTS;

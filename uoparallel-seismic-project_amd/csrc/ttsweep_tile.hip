@@ -65,6 +65,17 @@ init_tile_state_kernel(int2 *__restrict__ state, int NJ, int NK, int ntiles, int
     state[t] = make_int2(1, near_start ? 1 : 0);
 }
 
+// First hyperplane of the NEXT ordering sweep that can hold a due tile: a workgroup keeps the
+// minimum over the tiles it improved (every neighbour of such a tile is at most three
+// hyperplanes earlier) and adds it to one word at its end; the host starts the next sweep
+// there (ttsweep_driver.cpp: launch_pass_tile).  Every "look again" stamp is written next to a
+// call of this, so no due tile can lie in front of that hyperplane.
+__device__ __forceinline__ int tile_next_plane(const TileSweep &P, int I, int J, int K)
+{
+    const int In = P.nsx > 0 ? I : P.NI - 1 - I, Jn = P.nsy > 0 ? J : P.NJ - 1 - J, Kn = P.nsz > 0 ? K : P.NK - 1 - K;
+    return max(In + Jn + Kn - 3, 0);
+}
+
 // A tile of start-state `state` improved in this launch: its 27 neighbours have to look again.
 __device__ __forceinline__ void tile_stamp_neighbours(const TileSweep &P, int2 *__restrict__ state, int I, int J, int K,
                                                       int lane)
@@ -373,6 +384,7 @@ tile_sweep_kernel(TileSweep P)
     const long long W = P.wstride;              // workgroups of an XCD that take candidates (coprime to nactive)
     const long long nseq = (long long)P.NJ * ((P.NK + P.nxcd - 1) / P.nxcd) * P.nactive;   // candidates of an XCD
     TileWork work;
+    int first_next = INT_MAX;       // (uniform) see tile_next_plane
     for (long long q0 = blockIdx.x / P.nxcd; q0 < nseq && (long long)(blockIdx.x / P.nxcd) < W; q0 += 64 * W) {
       const TileCand pick = tile_candidate(P, q0 + lane * W, xcd, ncand);
       unsigned long long due_lanes = __ballot(pick.due);
@@ -530,6 +542,7 @@ tile_sweep_kernel(TileSweep P)
             }
             tile_stamp_neighbours(P, state, I, J, K, lane);
             tile_work_improved(work, act, lane);
+            first_next = min(first_next, tile_next_plane(P, I, J, K));
         }
         // (the image is overwritten by the next tile's loads: every read of it has been
         // consumed; the stores are in flight and read registers only)
@@ -547,6 +560,7 @@ tile_sweep_kernel(TileSweep P)
       }
     }
     tile_work_flush(P, work);
+    if (lane == 0 && first_next != INT_MAX) atomicMin(P.dmin_next, first_next);
 #ifdef TTSWEEP_TILE_PROFILE
     if (lane == 0 && prof_acc[4]) {
         for (int i = 0; i < 5; i++) atomicAdd(&g_tile_prof[i], prof_acc[i]);
@@ -688,6 +702,7 @@ tile_six_kernel(TileSweep P)
     const long long W = P.wstride;              // workgroups of an XCD that take candidates (coprime to nactive)
     const long long nseq = (long long)P.NJ * ((P.NK + P.nxcd - 1) / P.nxcd) * P.nactive;   // candidates of an XCD
     TileWork work;
+    int first_next = INT_MAX;       // (uniform) see tile_next_plane
     for (long long q0 = blockIdx.x / P.nxcd; q0 < nseq && (long long)(blockIdx.x / P.nxcd) < W; q0 += 64 * W) {
       const TileCand pick = tile_candidate(P, q0 + lane * W, xcd, ncand);
       unsigned long long due_lanes = __ballot(pick.due);
@@ -771,6 +786,7 @@ tile_six_kernel(TileSweep P)
             tface[tile_face_index(L, 1, K + 1, 0, 0, pa, pb)] = img[SIXC_T + row * TILE_Z + TILE_Z - 1];
             tile_stamp_neighbours(P, state, I, J, K, lane);
             tile_work_improved(work, act, lane);
+            first_next = min(first_next, tile_next_plane(P, I, J, K));
         }
 #ifdef TTSWEEP_TILE_PROFILE
         {
@@ -785,6 +801,7 @@ tile_six_kernel(TileSweep P)
       }
     }
     tile_work_flush(P, work);
+    if (lane == 0 && first_next != INT_MAX) atomicMin(P.dmin_next, first_next);
 #ifdef TTSWEEP_TILE_PROFILE
     if (lane == 0 && prof_acc[4]) {
         for (int i = 0; i < 5; i++) atomicAdd(&g_tile_prof[i], prof_acc[i]);
