@@ -19,7 +19,12 @@ json.dump(line("bench_line.json"), open(os.path.join(P, "r03_bench_line.json"), 
 shutil.copy(os.path.join(O, "bench_kernel_stats.csv"), os.path.join(P, "r03_bench_kernel_stats.csv"))
 json.dump(line("six1024_bench_line.json"), open(os.path.join(P, "r03_six1024_bench_line.json"), "w"), indent=1)
 shutil.copy(os.path.join(O, "six1024_kernel_stats.csv"), os.path.join(P, "r03_six1024_kernel_stats.csv"))
-shutil.copy(os.path.join(O, "six1024_launch_classes.txt"), os.path.join(P, "r03_six1024_launch_classes.txt"))
+txt = open(os.path.join(O, "six1024_launch_classes.txt")).read()
+txt = txt[:txt.index("sweeps (all solves)")] if "sweeps (all solves)" in txt else txt
+open(os.path.join(P, "r03_six1024_launch_classes.txt"), "w").write(
+    "tile_six_kernel launches of FOUR solves (warm-up, two timed, one instrumented) of six-FS 1024x1024x512 x 14, by duration\n"
+    "(rocprofv3 --kernel-trace, tools/exp/trace_six.py; 5188 launches per solve: the hyperplanes in front of the first\n"
+    "due tile of a sweep are not launched; per-sweep wall times of the dealing variants: r03_six1024_dealing.txt)\n\n" + txt)
 json.dump(line("six512_bench_line.json"), open(os.path.join(P, "r03_six512_bench_line.json"), "w"), indent=1)
 others = {k: line(f"{k}.json") for k in ("n3_line", "start4_line", "818_512_line", "818_1024_line", "prepass146_line",
                                          "prepass98_line", "n3_prepass98_line")}
