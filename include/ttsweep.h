@@ -97,6 +97,30 @@ typedef struct ttsweep_ctx ttsweep_ctx;
                                          (there: N = fsindex[3], the entries no longer than 4 cells,
                                          146 of the 818).  0 (default) switches it off. */
 
+#define TTSWEEP_OPT_ASYNC          9   /* schedule only, never the result: 1 = the STRIP kernel runs a solve as ONE
+                                         launch (no passes: planner workgroups hand the due units, nearest to
+                                         their start first, to the working workgroups through rings in device
+                                         memory, and detect convergence on the device); 0 = a launch pair per
+                                         pass; -1 (default) = the library chooses */
+#define TTSWEEP_OPT_ASYNC_LOW     10  /* schedule only: a ring is refilled when it holds at most this many ... */
+#define TTSWEEP_OPT_ASYNC_HIGH    11  /* ... up to this many units (0: defaults from the grid of workgroups) */
+#define TTSWEEP_OPT_ASYNC_SPECIAL 12  /* schedule only: units of a start between two relaxations of its
+                                         dead-edge cells in a one-launch solve (default 128) */
+#define TTSWEEP_OPT_ASYNC_POLICY  13  /* schedule only: how a planner hands units out in a one-launch solve.
+                                         0 = every refill of its ring starts at the unit nearest to the start
+                                         (strict priority by distance); 1 (default) = the scan goes round and
+                                         round the list, a unit at most once per round, behind the distance
+                                         gate (TTSWEEP_OPT_GATE_*: per round instead of per pass) */
+#define TTSWEEP_OPT_DEFER_MARGIN_MILLI 14 /* schedule only, never the result (STRIP kernel): an improvement is
+                                         reported at once only to the units that are not nearer to the start
+                                         than the improved cells by more than this many cells (x 1/1000, may be
+                                         negative); the units behind the front hear of it when the start is
+                                         otherwise at rest, once, instead of in every pass.  Default 0;
+                                         <= -1000000000 switches the deferral off */
+#define TTSWEEP_OPT_ASYNC_WINDOW_MILLI 15 /* schedule only: ring policy 2 - cells (x 1/1000) beyond the nearest unit
+                                         with anything to do up to which a start's units are handed out; 0 = no
+                                         gate */
+
 #define TTSWEEP_KERNEL_AUTO       0
 #define TTSWEEP_KERNEL_CELL       1   /* one thread per cell, star from global memory */
 #define TTSWEEP_KERNEL_STRIP      2   /* LDS-staged plane slabs, register strips */

@@ -184,6 +184,12 @@ void ttsweep_destroy(ttsweep_ctx *ctx)
     (void)hipFree(ctx->d_worklist);
     (void)hipFree(ctx->d_unitq);
     (void)hipFree(ctx->d_unitq_ctrl);
+    (void)hipFree(ctx->d_async_list);
+    (void)hipFree(ctx->d_async_ring_starts);
+    (void)hipFree(ctx->d_async_entries);
+    (void)hipFree(ctx->d_async_ctl);
+    (void)hipFree(ctx->d_async_status);
+    if (ctx->h_async_status) (void)hipHostFree(ctx->h_async_status);
     (void)hipFree(ctx->d_work);
     (void)hipFree(ctx->d_tile_wgwork);
     (void)hipFree(ctx->d_tile_dmin);
@@ -248,6 +254,30 @@ int ttsweep_set_option(ttsweep_ctx *ctx, int key, long long value)
     case TTSWEEP_OPT_PAIR_MIN_STARTS:
         if (value < 0) return set_error("start count must be >= 0");
         ctx->pair_min_starts = (int)std::min<long long>(value, 1 << 30);      // (>= 0: the explicit rule from now on)
+        return 0;
+    case TTSWEEP_OPT_ASYNC:
+        if (value < -1 || value > 1) return set_error("async mode must be -1, 0 or 1");
+        ctx->async_mode = (int)value;
+        return 0;
+    case TTSWEEP_OPT_ASYNC_LOW:
+    case TTSWEEP_OPT_ASYNC_HIGH:
+        if (value < 0 || value > 8192) return set_error("ring fill marks must lie in [0, 8192]");
+        (key == TTSWEEP_OPT_ASYNC_LOW ? ctx->async_low : ctx->async_high) = (int)value;
+        return 0;
+    case TTSWEEP_OPT_DEFER_MARGIN_MILLI:
+        ctx->defer_margin = value <= -1000000000ll ? -3.0e38f : (float)((double)value / 1000.0);
+        return 0;
+    case TTSWEEP_OPT_ASYNC_POLICY:
+        if (value < 0 || value > 2) return set_error("ring policy must be 0, 1 or 2");
+        ctx->async_policy = (int)value;
+        return 0;
+    case TTSWEEP_OPT_ASYNC_WINDOW_MILLI:
+        if (value < 0) return set_error("window must be >= 0");
+        ctx->async_window = (float)((double)value / 1000.0);
+        return 0;
+    case TTSWEEP_OPT_ASYNC_SPECIAL:
+        if (value < 1) return set_error("dead-edge interval must be positive");
+        ctx->async_special_every = (int)std::min<long long>(value, 1 << 30);
         return 0;
     case TTSWEEP_OPT_GATE_R0_MILLI:
         if (value < 0) return set_error("gate start radius must be >= 0");

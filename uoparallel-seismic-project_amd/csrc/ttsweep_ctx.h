@@ -95,6 +95,20 @@ struct ttsweep_ctx {
     // per pass (measured, 818-offset star: 3.5 cells/pass gives the shortest solve).
     double gate_speed = 0.0;                // 0: no gate
     double gate_r0 = 0.0;
+    // STRIP: bits for units nearer to the start than the improved cells by more than this many cells are
+    // deferred until the start is otherwise at rest (push_improved); < -1e30: off
+    float defer_margin = 0.f;
+    // STRIP, one launch per solve (AsyncSolve, ttsweep_dev.h)
+    int async_mode = -1;                    // TTSWEEP_OPT_ASYNC
+    int async_low = 0, async_high = 0;      // 0: defaults (solve_async_strip)
+    int async_special_every = 128;
+    int async_policy = 2;                   // TTSWEEP_OPT_ASYNC_POLICY
+    float async_window = 16.f;              // TTSWEEP_OPT_ASYNC_WINDOW_MILLI
+    int4 *d_async_list = nullptr;           // the rings' unit lists
+    size_t async_list_cap = 0;
+    int *d_async_ring_starts = nullptr;     // ASYNC_MAX_STARTS
+    unsigned long long *d_async_entries = nullptr, *d_async_ctl = nullptr;
+    unsigned *d_async_status = nullptr, *h_async_status = nullptr;     // (pinned)
     // TILE kernel: the star in device axes, halo of the staged image, launch counter
     TileEntry tile_ent[ttsweep::TILE_MAX_ENT];
     int tile_nent = 0, tile_R = 1, tile_fz = 1;     // entries, max |da|,|db|, max |dc| of the star
@@ -164,10 +178,11 @@ void make_layout(ttsweep_ctx *ctx);                     // padded layout of ctx-
 int upload_star(ttsweep_ctx *ctx);                      // pull star (CELL kernel, dead-edge cells, validator)
 int upload_strip_plan(ttsweep_ctx *ctx);                // the STRIP kernel's items, one- and two-plane units
 void fill_special_box(const ttsweep_ctx *ctx, StartDesc &sd);   // dead-edge box of one start
-size_t flag_words(const DevLayout &L);                  // activity words per start
+size_t flag_words(const DevLayout &L, int kernel);      // activity words per start (of kernel variant `kernel`)
 int ensure_capacity(ttsweep_ctx *ctx, int nstart);      // per-solve pools for nstart starts
 size_t per_start_device_bytes(const ttsweep_ctx *ctx);  // what ensure_capacity allocates per start
 int build_worklist(ttsweep_ctx *ctx, int nactive);      // STRIP: static unit list of the active starts
+int ensure_unit_grid(ttsweep_ctx *ctx);                 // STRIP: ctx->unitq_blocks = workgroups the device holds at once
 void order_units(const ttsweep_ctx *ctx, const StartDesc &sd, std::vector<int> &order);
 
 // ---- ttsweep_driver.cpp ----------------------------------------------------

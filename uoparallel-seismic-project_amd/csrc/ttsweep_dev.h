@@ -138,6 +138,60 @@ struct UnitPassTail {
     int nstart;                 // "changed" words per pass
     int *changed_host;          // pinned host copy of this pass's words (written at the end)
     int *changed_next;          // the next pass's device words (cleared at the end)
+    float defer_margin;         // DeferRule::margin of the solve (ttsweep_kernels.hip, push_improved)
+};
+
+// ---------------------------------------------------------------------------
+// STRIP, one launch per solve (sweep_units_kernel<.., ASYNC = true>, DESIGN.md 4.1 "No passes")
+// ---------------------------------------------------------------------------
+// The pass structure is gone: the grid is launched ONCE per solve.  The starts are dealt over
+// `nrings` rings (at most one per XCD); the first nrings workgroups are PLANNERS, one per ring:
+// a planner scans its ring's static unit list (every unit of its starts, nearest to the start
+// first) for units whose pend word holds staged-plane bits, marks them busy and publishes them
+// into the ring, nearest first, but only while the ring holds fewer than `high` entries - so
+// far units are handed out only when near work has run dry (a priority queue by distance, made
+// of a scan order and a bounded FIFO).  All other workgroups are WORKERS: they claim ring
+// entries (own XCD's ring first), relax the unit exactly as a pass does, RELEASE their stores
+// (agent scope), push the plane bits to the neighbours' pend words, clear the unit's busy bit
+// and count the unit as completed.  A ring is finished when a whole scan found no bit, nothing
+// was queued or running when the scan began, and the dead-edge cells of its starts have been
+// relaxed since the last unit: its planner sets the done bit; a worker leaves when every ring
+// is done.  Every word that workgroups exchange is accessed with agent-scope atomics only; the
+// travel times themselves cross workgroups behind a release (storing side) / acquire (after a
+// ring entry has been read) pair of agent-scope fences.
+constexpr int ASYNC_MAX_RINGS = 8;
+constexpr int ASYNC_CTL_STRIDE = 32;                    // 64-bit words per ring: [0] head | tail << 32 | done << 63,
+                                                        // [16] (low half) units completed
+constexpr int ASYNC_RING_STARTS = 32;                   // starts per ring, at most
+constexpr unsigned ASYNC_BUSY = 0x80000000u;            // pend word: the unit is queued or being relaxed
+constexpr unsigned ASYNC_UNIT_SPECIAL = 0xfffffu;       // ring entry: relax the start's dead-edge cells
+constexpr unsigned long long ASYNC_EXIT = ~0ull;
+constexpr int ASYNC_MAX_STARTS = 255;                   // (8 bits of a ring entry; 255 keeps ASYNC_EXIT apart)
+// ring entry: planes (16) | unit (20) << 16 | start (8) << 36 | position in the ring mod 2^20 << 44
+enum : int { ASYNC_OK = 0, ASYNC_ERR_TIMEOUT = 1, ASYNC_ERR_CAP = 2 };
+
+struct AsyncSolve {
+    int nrings;
+    int cap_mask;                   // ring capacity - 1 (a power of two)
+    int low, high;                  // the planner refills a ring that holds <= low entries up to high
+    int special_every;              // units of a start between two relaxations of its dead-edge cells
+    const int4 *list;               // the rings' unit lists, one after the other: (start | index in ring << 16, unit,
+                                    // squared distance from the start to the unit in cells (float bits), 0)
+    int policy;                     // 0: every refill scans from the nearest unit on (strict priority by distance);
+                                    // 1: the scan goes round and round the list (a unit is handed out at most once
+                                    //    per round) behind a distance gate that opens by gate_speed cells per round
+                                    // 2: as 1, but the gate of a start lies `window` cells beyond the nearest of its
+                                    //    units that the previous round found with anything to do
+    float gate_r0, gate_speed;      // policy 1; speed <= 0: no gate
+    float window;                   // policy 2; <= 0: no gate
+    int ring_off[ASYNC_MAX_RINGS], ring_len[ASYNC_MAX_RINGS];
+    int ring_start_off[ASYNC_MAX_RINGS + 1];    // ring r serves starts ring_starts[ring_start_off[r] .. [r + 1])
+    const int *ring_starts;
+    unsigned long long *entries;    // nrings x (cap_mask + 1), all ones before the launch
+    unsigned long long *ctl;        // nrings x ASYNC_CTL_STRIDE, zero before the launch
+    unsigned *status;               // [0]: ASYNC_OK or the first error
+    long long timeout_ticks;        // wall-clock ticks (100 MHz) after which every wait gives up
+    long long max_entries;          // entries a ring may publish before the solve counts as not converging
 };
 
 // ---------------------------------------------------------------------------

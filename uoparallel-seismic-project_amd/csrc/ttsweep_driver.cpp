@@ -8,6 +8,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 
 namespace ttsweep {
 
@@ -42,7 +43,7 @@ static int launch_pass_strip(ttsweep_ctx *ctx, int nactive, int nstart, int *d_c
     const StripPlan &plan = ctx->plans[ctx->np - 1];
     HIPCHK(launch_plan_pass(ctx->L, ctx->d_starts, ctx->d_worklist, ctx->worklist_len, d_changed,
                             ctx->d_unitq, (int)ctx->unitq_cap, ctx->nlists, ctx->d_unitq_ctrl,
-                            plan, gate_r2(ctx), ctx->d_tile_flags, (long long)flag_words(ctx->L), ctx->stream));
+                            plan, gate_r2(ctx), ctx->d_tile_flags, (long long)flag_words(ctx->L, ctx->kernel), ctx->stream));
     UnitPassTail tail;
     tail.active = ctx->d_active;
     tail.nactive = nactive;
@@ -52,6 +53,7 @@ static int launch_pass_strip(ttsweep_ctx *ctx, int nactive, int nstart, int *d_c
     tail.nstart = nstart;
     tail.changed_host = h_changed_slot;
     tail.changed_next = d_changed_next;
+    tail.defer_margin = ctx->defer_margin;
     HIPCHK(launch_sweep_units(ctx->L, ctx->d_v, ctx->d_starts, ctx->d_unitq, (int)ctx->unitq_cap,
                               ctx->nlists, ctx->d_unitq_ctrl, ctx->unitq_blocks, d_changed,
                               ctx->d_strip_items[ctx->np - 1], plan, tail, ctx->stream));
@@ -74,7 +76,7 @@ static int prepare_tile_sweep(ttsweep_ctx *ctx)
     P.nent = ctx->tile_nent;
     P.T0 = ctx->d_T;
     P.state0 = ctx->d_tile_flags;
-    P.state_stride = (long long)flag_words(ctx->L);
+    P.state_stride = (long long)flag_words(ctx->L, ctx->kernel);
     P.work0 = ctx->d_work;
     P.fz = ctx->tile_fz;
     P.vface = ctx->d_vface;
@@ -179,6 +181,130 @@ static int launch_pass(ttsweep_ctx *ctx, int nactive, int nstart, int *d_changed
     return 0;
 }
 
+// STRIP, one launch per solve (AsyncSolve, ttsweep_dev.h): can this solve run that way, and should it?
+static bool use_async(const ttsweep_ctx *ctx, int nstart)
+{
+    if (ctx->kernel != TTSWEEP_KERNEL_STRIP || ctx->async_mode == 0) return false;
+    if (nstart > ASYNC_MAX_STARTS || strip_units(ctx->L, ctx->np) >= (int)ASYNC_UNIT_SPECIAL) return false;
+    return ctx->async_mode == 1;
+}
+
+// The whole driver loop as one launch: the rings' lists (every unit of a ring's starts, nearest
+// first, the starts interleaved rank by rank), the ring memory, the launch, its verdict.
+// sweeps[s]: whole-grid equivalents of units relaxed for start s (what a pass count is for the
+// pass driver).  Returns 1 / 0 (something improved / nothing did) or < 0.
+static int solve_async_strip(ttsweep_ctx *ctx, int nstart, bool single_source, std::vector<int> &sweeps)
+{
+    const StripPlan &plan = ctx->plans[ctx->np - 1];
+    const int nunits = strip_units(ctx->L, ctx->np);
+    if (ensure_unit_grid(ctx)) return -1;
+    AsyncSolve as{};
+    as.nrings = std::min(std::min(nstart, ctx->nlists), (int)ASYNC_MAX_RINGS);
+    const int cap = 1 << 14;
+    as.cap_mask = cap - 1;
+    const int workers = std::max((ctx->unitq_blocks - as.nrings) / as.nrings, 1);
+    as.low = ctx->async_low > 0 ? ctx->async_low : std::max(workers / 2, 8);
+    as.high = ctx->async_high > 0 ? ctx->async_high : 2 * workers;
+    as.high = std::max(as.high, as.low + 1);
+    as.special_every = ctx->async_special_every;
+    // lists
+    as.policy = ctx->async_policy;
+    as.gate_r0 = (float)ctx->gate_r0;
+    as.gate_speed = single_source ? (float)ctx->gate_speed : 0.f;      // (the gate is for solves that grow from one unit)
+    as.window = single_source ? ctx->async_window : 0.f;
+    const int btiles = strip_btiles(ctx->L), cstrips = strip_cstrips(ctx->L);
+    auto gate_d2 = [&](int s, int unit) {       // squared distance from the start to the unit's cells (plan_pass_kernel)
+        const StartDesc &sd = ctx->h_starts[s];
+        const int cs = unit % cstrips, bt = (unit / cstrips) % btiles, a0 = ctx->np * (unit / (cstrips * btiles));
+        const int b0 = bt * STRIP_TB, cb0 = cs * STRIP_K, tb_eff = std::min((int)STRIP_TB, ctx->L.n[1]);
+        const float da = (float)std::max(std::max(a0 - sd.sa, sd.sa - (a0 + ctx->np - 1)), 0);
+        const float db = (float)std::max(std::max(b0 - sd.sb, sd.sb - (b0 + tb_eff - 1)), 0);
+        const float dc = (float)std::max(std::max(cb0 - sd.sc, sd.sc - (cb0 + STRIP_K - 1)), 0);
+        const float d2 = da * da + db * db + dc * dc;
+        int bits;
+        memcpy(&bits, &d2, sizeof bits);
+        return bits;
+    };
+    std::vector<int4> flat;
+    flat.reserve((size_t)nstart * nunits);
+    std::vector<int> ring_starts;
+    for (int r = 0; r < as.nrings; r++) {
+        as.ring_off[r] = (int)flat.size();
+        as.ring_start_off[r] = (int)ring_starts.size();
+        std::vector<int> mine;
+        for (int a = r; a < nstart; a += as.nrings) mine.push_back(a);
+        if ((int)mine.size() > ASYNC_RING_STARTS) return set_error("too many starts for a one-launch solve");
+        for (int a : mine) ring_starts.push_back(a);
+        for (int k = 0; k < nunits; k++)
+            for (size_t i = 0; i < mine.size(); i++)
+                flat.push_back(make_int4(mine[i] | ((int)i << 16), ctx->unit_order[mine[i]][k],
+                                         gate_d2(mine[i], ctx->unit_order[mine[i]][k]), 0));
+        as.ring_len[r] = (int)flat.size() - as.ring_off[r];
+    }
+    as.ring_start_off[as.nrings] = (int)ring_starts.size();
+    if (flat.size() > ctx->async_list_cap) {
+        if (ctx->d_async_list) HIPCHK(hipFree(ctx->d_async_list));
+        ctx->d_async_list = nullptr;
+        ctx->async_list_cap = 0;
+        HIPCHK(hipMalloc((void **)&ctx->d_async_list, flat.size() * sizeof(int4)));
+        ctx->async_list_cap = flat.size();
+    }
+    if (!ctx->d_async_ring_starts) HIPCHK(hipMalloc((void **)&ctx->d_async_ring_starts, ASYNC_MAX_STARTS * sizeof(int)));
+    if (!ctx->d_async_entries) HIPCHK(hipMalloc((void **)&ctx->d_async_entries, (size_t)ASYNC_MAX_RINGS * cap * sizeof(unsigned long long)));
+    if (!ctx->d_async_ctl) HIPCHK(hipMalloc((void **)&ctx->d_async_ctl, (size_t)ASYNC_MAX_RINGS * ASYNC_CTL_STRIDE * sizeof(unsigned long long)));
+    if (!ctx->d_async_status) HIPCHK(hipMalloc((void **)&ctx->d_async_status, 8 * sizeof(unsigned)));
+    if (!ctx->h_async_status) HIPCHK(hipHostMalloc((void **)&ctx->h_async_status, 8 * sizeof(unsigned)));
+    HIPCHK(hipMemcpyAsync(ctx->d_async_list, flat.data(), flat.size() * sizeof(int4), hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(hipMemcpyAsync(ctx->d_async_ring_starts, ring_starts.data(), ring_starts.size() * sizeof(int),
+                          hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(hipMemsetAsync(ctx->d_async_entries, 0xff, (size_t)ASYNC_MAX_RINGS * cap * sizeof(unsigned long long), ctx->stream));
+    HIPCHK(hipMemsetAsync(ctx->d_async_ctl, 0, (size_t)ASYNC_MAX_RINGS * ASYNC_CTL_STRIDE * sizeof(unsigned long long), ctx->stream));
+    HIPCHK(hipMemsetAsync(ctx->d_async_status, 0, 8 * sizeof(unsigned), ctx->stream));
+    HIPCHK(hipMemsetAsync(ctx->d_changed, 0, (size_t)nstart * sizeof(int), ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));      // (`flat` is a stack-lifetime buffer)
+    as.list = ctx->d_async_list;
+    as.ring_starts = ctx->d_async_ring_starts;
+    as.entries = ctx->d_async_entries;
+    as.ctl = ctx->d_async_ctl;
+    as.status = ctx->d_async_status;
+    as.timeout_ticks = 10ll * 100000000ll;          // ten seconds of wall clock (100 MHz): far beyond any solve this mode is chosen for
+    long long longest = 0;
+    for (int r = 0; r < as.nrings; r++) longest = std::max<long long>(longest, as.ring_len[r]);
+    as.max_entries = (long long)std::min<double>((double)ctx->max_sweeps * (double)longest, 2.0e9);
+
+    UnitPassTail tail{};
+    tail.entries = ctx->d_cell_entries;
+    tail.nentries = ctx->n_cell_entries;
+    tail.max_box_cells = (int)ctx->max_box_cells;
+    tail.nstart = nstart;
+    tail.defer_margin = ctx->defer_margin;
+    hipEvent_t e0, e1;
+    if (ctx->timing && timed_event(ctx, &e0)) return -1;
+    HIPCHK(launch_solve_units(ctx->L, ctx->d_v, ctx->d_starts, ctx->unitq_blocks, ctx->d_changed,
+                              ctx->d_strip_items[ctx->np - 1], plan, tail, as, ctx->d_tile_flags,
+                              (long long)flag_words(ctx->L, ctx->kernel), ctx->stream));
+    if (ctx->timing && timed_event(ctx, &e1)) return -1;
+    ctx->stats.launches++;
+    HIPCHK(hipMemcpyAsync(ctx->h_async_status, ctx->d_async_status, 8 * sizeof(unsigned), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipMemcpyAsync(ctx->h_changed, ctx->d_changed, (size_t)nstart * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipMemcpyAsync(ctx->h_work, ctx->d_work, 3 * nstart * sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+#ifdef TTSWEEP_ASYNC_STATS
+    fprintf(stderr, "one-launch solve: %u units (%u staged planes) relaxed, %u units (%u planes) improved nothing\n",
+            ctx->h_async_status[4], ctx->h_async_status[5], ctx->h_async_status[6], ctx->h_async_status[7]);
+#endif
+    if (ctx->h_async_status[0] == ASYNC_ERR_CAP)
+        return set_error("a start did not converge in %lld sweeps", ctx->max_sweeps);
+    if (ctx->h_async_status[0] != ASYNC_OK)
+        return set_error("the one-launch solve gave up (code %u)", ctx->h_async_status[0]);
+    bool any = false;
+    for (int s = 0; s < nstart; s++) {
+        any |= (ctx->h_changed[s] & CHANGED_IMPROVED) != 0;
+        sweeps[s] = (int)((ctx->h_work[3 * s + 2] + (unsigned long long)nunits - 1) / (unsigned long long)nunits);
+    }
+    return any ? 1 : 0;
+}
+
 int solve_device_body(ttsweep_ctx *ctx, int nstart, const ttsweep_start *starts,
                              float *const *tt_dev, int init)
 {
@@ -207,7 +333,7 @@ int solve_device_body(ttsweep_ctx *ctx, int nstart, const ttsweep_start *starts,
             for (int d = 0; d < 3; d++) vol *= std::max(sd.box_hi[d] - sd.box_lo[d] + 1, 0);
             ctx->max_box_cells = std::max<long long>(s == 0 ? 0 : ctx->max_box_cells, vol);
         }
-        sd.tile_flags = ctx->d_tile_flags + (size_t)s * flag_words(L);
+        sd.tile_flags = ctx->d_tile_flags + (size_t)s * flag_words(L, ctx->kernel);
         sd.work = ctx->d_work + 3 * s;
         if (init) HIPCHK(launch_init_tt(L, sd.T, sd.sidx, ctx->stream));
         else HIPCHK(launch_pack(L, tt_dev[s], sd.T, INFINITY, ctx->stream));
@@ -243,7 +369,8 @@ int solve_device_body(ttsweep_ctx *ctx, int nstart, const ttsweep_start *starts,
     ctx->pass_index = 0;
     ctx->tile_epoch = 1;
     if (ctx->kernel == TTSWEEP_KERNEL_TILE && prepare_tile_sweep(ctx)) return -1;
-    if (ctx->kernel == TTSWEEP_KERNEL_STRIP) {
+    const bool async = use_async(ctx, nstart);
+    if (ctx->kernel == TTSWEEP_KERNEL_STRIP && !async) {
         if (build_worklist(ctx, nstart)) return -1;
         // the passes keep these cleared themselves from here on
         HIPCHK(hipMemsetAsync(ctx->d_changed, 0, (size_t)PASS_SLOTS * nstart * sizeof(int), ctx->stream));
@@ -270,6 +397,13 @@ int solve_device_body(ttsweep_ctx *ctx, int nstart, const ttsweep_start *starts,
     const int depth = ctx->kernel == TTSWEEP_KERNEL_TILE ? 1 : 2;
     bool anychange_ever = false;
     auto t_pass = std::chrono::steady_clock::now();
+    if (async) {
+        const int rc = solve_async_strip(ctx, nstart, init != 0, sweeps);
+        if (rc < 0) return rc;
+        anychange_ever = rc > 0;
+        nactive = 0;
+    }
+    for (;;) {
     while (processed < launched || nactive > 0) {
         if (nactive > 0 && launched - processed < depth) {      // enqueue the next pass
             const int slot = launched % PASS_SLOTS;
@@ -342,6 +476,25 @@ int solve_device_body(ttsweep_ctx *ctx, int nstart, const ttsweep_start *starts,
                 HIPCHK(hipStreamSynchronize(ctx->stream));
             }
         }
+    }
+
+        // STRIP: every start is at rest; the bits that were deferred (push_improved: units behind the
+        // front) become due now, and the starts that had any go on
+        if (ctx->kernel != TTSWEEP_KERNEL_STRIP || async || ctx->defer_margin < -1.0e30f) break;
+        for (int s = 0; s < nstart; s++) ctx->h_active[s] = s;
+        int *const dfl = ctx->d_changed + (size_t)PASS_SLOTS * nstart, *const hfl = ctx->h_changed + (size_t)PASS_SLOTS * nstart;
+        HIPCHK(hipMemcpyAsync(ctx->d_active, ctx->h_active, nstart * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
+        HIPCHK(hipMemsetAsync(dfl, 0, nstart * sizeof(int), ctx->stream));
+        HIPCHK(launch_flush_deferred(L, ctx->np, ctx->d_tile_flags, (long long)flag_words(L, ctx->kernel), ctx->d_active,
+                                     nstart, dfl, ctx->stream));
+        HIPCHK(hipMemcpyAsync(hfl, dfl, nstart * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(hipStreamSynchronize(ctx->stream));
+        nactive = 0;
+        for (int s = 0; s < nstart; s++)
+            if (hfl[s]) { ctx->h_active[nactive++] = s; done[s] = 0; }
+        if (nactive == 0) break;
+        HIPCHK(hipMemcpyAsync(ctx->d_active, ctx->h_active, nactive * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
+        if (build_worklist(ctx, nactive)) return -1;
     }
 
     for (int s = 0; s < nstart; s++)

@@ -64,6 +64,16 @@ hipError_t launch_sweep_units(const DevLayout &L, const float *v, const StartDes
                               const int4 *lists, int list_cap, int nlists, int *ctrl, int nblocks,
                               int *changed, const StripItem *items, const StripPlan &plan,
                               const UnitPassTail &tail, hipStream_t st);
+// One launch per solve (AsyncSolve, ttsweep_dev.h): the first as.nrings workgroups plan, the others
+// relax; returns when every ring is at rest.  tail: only entries / nentries / max_box_cells are used.
+hipError_t launch_solve_units(const DevLayout &L, const float *v, const StartDesc *starts, int nblocks,
+                              int *changed, const StripItem *items, const StripPlan &plan,
+                              const UnitPassTail &tail, const AsyncSolve &as, int *flags0, long long flags_stride,
+                              hipStream_t st);
+// pend |= defer, defer = 0 for the units of the listed starts (np planes per unit); changed[s] |=
+// CHANGED_PENDING where a bit moved (push_improved: bits for units nearer to the start are deferred)
+hipError_t launch_flush_deferred(const DevLayout &L, int np, int *flags0, long long flags_stride,
+                                 const int *active, int nactive, int *changed, hipStream_t st);
 // First activity words of a start: from_box = false: only the start's patch is a source;
 // from_box = true: every patch that holds a finite travel time is one.  (ra, np: the reach of
 // the star along the plane axis and the planes per unit of the solve.)

@@ -726,14 +726,39 @@ hipError_t launch_init_tile_flags(const DevLayout &L, const StartDesc &sd, bool 
 // the improvement lay within reach of the shared border (flag_bit).  The planner then reads
 // ONE word per unit (round 2: it gathered 9 flag words per staged plane, 144 per unit of two
 // planes, in every pass).
+// Deferral (DeferRule).  Most improvements matter only to the units FARTHER from the start than
+// the cells that improved: the units behind a front have their final values (or nearly), and
+// relaxing them again for every improvement in front of them finds nothing (measured: 47 % of the
+// unit relaxations of a solve improved no cell).  A bit for a unit whose centre is nearer to the
+// start than the improved patch's by more than `margin` cells is therefore not put into the unit's
+// pend word but into its `defer` word (first block of StartDesc::tile_flags), which nobody looks at
+// until the start is otherwise at rest; then the deferred bits become pend bits (flush_deferred /
+// the ring planner) and the solve goes on until both kinds are gone.  Every bit is honoured in
+// the end - after the last change of the plane it stands for -, so the fixed point is the same;
+// what is saved is the repetition: a deferred (unit, plane) pair is relaxed once, against final
+// values, instead of once per pass in which the plane changed.  Where the geometry misleads
+// (a fast path that runs back towards the start) the late relaxation improves cells and the solve
+// simply continues from there.
+struct DeferRule {
+    int sa, sb, sc;         // the start (device axes)
+    float margin;           // cells; < -1e30: nothing is deferred
+};
+
 template <int NP>
 __device__ __forceinline__ void push_improved(const DevLayout &L, int ra, int btiles, int cstrips,
-                                              unsigned *__restrict__ pend, int a, int bt, int cs, int improved, int lane)
+                                              unsigned *__restrict__ pend, int a, int bt, int cs, int improved, int lane,
+                                              const DeferRule &rule, unsigned *__restrict__ defer)
 {
     const int lo_num = a - ra - NP + 1;                                 // A' >= ceil(lo_num / NP)
     const int Alo = max(NP == 1 ? lo_num : (lo_num + 1) >> 1, 0);
     const int Ahi = min((a + ra) / NP, strip_agroups(L, NP) - 1);
     const int n = (Ahi - Alo + 1) * 9;
+    const float half_b = 0.5f * (float)min(STRIP_TB, L.n[1]);
+    // distance of the improved patch from the start, less the margin: a target nearer than that is deferred
+    const float sda = (float)(a - rule.sa), sdb = (float)(bt * STRIP_TB - rule.sb) + half_b,
+                sdc = (float)(cs * STRIP_K - rule.sc) + 0.5f * STRIP_K;
+    const float lim = sqrtf(sda * sda + sdb * sdb + sdc * sdc) - rule.margin;
+    const float lim2 = lim > 0.f && rule.margin > -1.0e30f ? lim * lim : -1.f;
     for (int idx = lane; idx < n; idx += 64) {
         const int A = Alo + idx / 9, r = idx % 9;
         const int db = r / 3 - 1, dc = r % 3 - 1;
@@ -741,9 +766,42 @@ __device__ __forceinline__ void push_improved(const DevLayout &L, int ra, int bt
         // the unit above / behind reads across our high border: our HI zone matters to it
         const int need = flag_bit(db == 1 ? ZONE_HI : db == -1 ? ZONE_LO : ZONE_ANY,
                                   dc == 1 ? ZONE_HI : dc == -1 ? ZONE_LO : ZONE_ANY);
-        if (nb >= 0 && nb < btiles && nc >= 0 && nc < cstrips && (improved & need))
-            atomicOr(&pend[(A * btiles + nb) * cstrips + nc], 1u << (a - (NP * A - ra)));
+        if (nb >= 0 && nb < btiles && nc >= 0 && nc < cstrips && (improved & need)) {
+            const float tda = (float)(NP * A - rule.sa) + 0.5f * (NP - 1), tdb = (float)(nb * STRIP_TB - rule.sb) + half_b,
+                        tdc = (float)(nc * STRIP_K - rule.sc) + 0.5f * STRIP_K;
+            const bool later = tda * tda + tdb * tdb + tdc * tdc < lim2;
+            atomicOr(&(later ? defer : pend)[(A * btiles + nb) * cstrips + nc], 1u << (a - (NP * A - ra)));
+        }
     }
+}
+
+// pend |= defer, defer = 0 for every unit of the starts listed in `active` (one thread per unit and
+// start); changed[s] |= CHANGED_PENDING where a bit moved.  The pass driver runs it when every
+// start is at rest.
+__global__ void __launch_bounds__(256)
+flush_deferred_kernel(int *__restrict__ flags0, long long flags_stride, int nflag, int nunits,
+                      const int *__restrict__ active, int *__restrict__ changed)
+{
+    const int unit = blockIdx.x * 256 + threadIdx.x;
+    const int s = active[blockIdx.y];
+    if (unit >= nunits) return;
+    unsigned *const defer = reinterpret_cast<unsigned *>(flags0 + (long long)s * flags_stride);
+    const unsigned d = defer[unit];
+    if (d) {
+        defer[unit] = 0;
+        atomicOr(defer + 2 * nflag + unit, d);
+        atomicOr(&changed[s], CHANGED_PENDING);
+    }
+}
+
+hipError_t launch_flush_deferred(const DevLayout &L, int np, int *flags0, long long flags_stride,
+                                 const int *active, int nactive, int *changed, hipStream_t st)
+{
+    if (nactive <= 0) return hipSuccess;
+    const int nunits = strip_units(L, np);
+    hipLaunchKernelGGL(flush_deferred_kernel, dim3((nunits + 255) / 256, nactive), dim3(256), 0, st,
+                       flags0, flags_stride, strip_flag_words(L), nunits, active, changed);
+    return hipGetLastError();
 }
 
 // First pend words of a start, from the patch flags the initialisation kernels leave in the
@@ -874,11 +932,12 @@ plan_pass_kernel(DevLayout L, const StartDesc *__restrict__ starts, const int2 *
 // PULL_REV entries iff the neighbour is).  Called by every wave of sweep_units_kernel
 // before it turns to the unit queues.
 // ---------------------------------------------------------------------------
+template <bool ASYNC = false>
 __device__ __forceinline__ void relax_special_cell(const DevLayout &L, const float *__restrict__ v,
                                                    const StartDesc &sd, int s, int cell,
                                                    int *__restrict__ changed,
                                                    const CellEntry *__restrict__ entries,
-                                                   int nentries, int ra, int np, int lane)
+                                                   int nentries, int ra, int np, int lane, float defer_margin)
 {
     const int ea = sd.box_hi[0] - sd.box_lo[0] + 1;
     const int eb = sd.box_hi[1] - sd.box_lo[1] + 1;
@@ -926,10 +985,17 @@ __device__ __forceinline__ void relax_special_cell(const DevLayout &L, const flo
         atomicOr(&changed[s], CHANGED_IMPROVED);
     }
     if (better) {
+        if (ASYNC) {    // one launch per solve: the store is released before anybody is told about it
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
         const int btiles = strip_btiles(L), cstrips = strip_cstrips(L);
         unsigned *const pend = reinterpret_cast<unsigned *>(sd.tile_flags + 2 * strip_flag_words(L));
-        if (np == 1) push_improved<1>(L, ra, btiles, cstrips, pend, a, b / STRIP_TB, c / STRIP_K, FLAG_ALL, lane);
-        else push_improved<2>(L, ra, btiles, cstrips, pend, a, b / STRIP_TB, c / STRIP_K, FLAG_ALL, lane);
+        const DeferRule rule{sd.sa, sd.sb, sd.sc, defer_margin};
+        unsigned *const defer = reinterpret_cast<unsigned *>(sd.tile_flags);
+        if (np == 1) push_improved<1>(L, ra, btiles, cstrips, pend, a, b / STRIP_TB, c / STRIP_K, FLAG_ALL, lane, rule, defer);
+        else push_improved<2>(L, ra, btiles, cstrips, pend, a, b / STRIP_TB, c / STRIP_K, FLAG_ALL, lane, rule, defer);
     }
 }
 
@@ -1011,12 +1077,298 @@ void prof_dump()
 #endif
 int units_wgs_per_cu() { return TTSWEEP_WGS_GRID; }
 
-template <int K, int NP>
+// ---------------------------------------------------------------------------
+// one launch per solve (AsyncSolve, ttsweep_dev.h): ring planner and ring claims
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ unsigned long long ald64(const unsigned long long *p)
+{
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ unsigned ald32(const unsigned *p)
+{
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void async_fail(const AsyncSolve &as, unsigned code)
+{
+    atomicCAS(as.status, (unsigned)ASYNC_OK, code);
+}
+
+// Planner of ring r: all 256 threads of one workgroup.  `lds`: scratch words of its own.
+template <int NP>
+__device__ __noinline__ void async_planner(const DevLayout &L, const StartDesc *__restrict__ starts, const AsyncSolve &as,
+                                           const int r, const int btiles, const int cstrips, const int ra,
+                                           const PlaneCounts &pc, int *__restrict__ flags0, const long long flags_stride,
+                                           int *lds)
+{
+    const int tid = threadIdx.y * STRIP_TB + threadIdx.x, lane = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.y);
+    const int4 *__restrict__ list = as.list + as.ring_off[r];
+    const int n = as.ring_len[r];
+    unsigned long long *const ht = as.ctl + (size_t)r * ASYNC_CTL_STRIDE;
+    unsigned *const completed = reinterpret_cast<unsigned *>(ht + 16);
+    unsigned long long *const ents = as.entries + (size_t)r * (size_t)(as.cap_mask + 1);
+    const int ns = as.ring_start_off[r + 1] - as.ring_start_off[r];
+    const int *__restrict__ rstarts = as.ring_starts + as.ring_start_off[r];
+    const int nflag = L.n[0] * btiles * cstrips;
+    constexpr int KSCAN = 4;                    // list entries per thread and scan step
+    int *sh = lds;                              // [0] head, [1] completed, [2] stop
+    int *cnt = lds + 8;                         // [KSCAN][waves] due units found
+    int *dirty = lds + 8 + KSCAN * STRIP_NS;    // [ASYNC_RING_STARTS] units published since the start's last special
+    int *minact = dirty + ASYNC_RING_STARTS;    // [ASYNC_RING_STARTS] smallest squared distance (float bits) met with work, this round
+    float *gate2 = reinterpret_cast<float *>(minact + ASYNC_RING_STARTS);      // [ASYNC_RING_STARTS] squared gate radius per start
+    if (tid < ASYNC_RING_STARTS) {
+        dirty[tid] = tid < ns ? 1 : 0;          // (the first thing a ring does: its starts' dead-edge cells)
+        minact[tid] = 0;                        // (the first round: the window around the start itself)
+        gate2[tid] = 3.0e38f;
+    }
+    __syncthreads();
+    unsigned t = 0;                             // entries published so far (uniform)
+    const long long clock0 = wall_clock64();
+    // state of the scan in progress (uniform but `activity`): where it continues, which round it belongs to,
+    // whether the ring was at rest when it began, whether it met a word that was not zero
+    int base = n, round = -1, activity = 0;
+    bool quiet = false;
+    float gate_r2 = 3.0e38f;
+
+    // publishes the dead-edge entries of the ring's starts whose counter has reached `threshold`
+    auto publish_specials = [&](int threshold) -> int {
+        int total = 0;
+        if (wave == 0) {
+            const bool need = lane < ns && dirty[lane] >= threshold;
+            const unsigned long long bal = __ballot(need);
+            if (need) {
+                const unsigned pos = t + (unsigned)__popcll(bal & ((1ull << lane) - 1ull));
+                const unsigned long long e = 0xffffull | ((unsigned long long)ASYNC_UNIT_SPECIAL << 16)
+                                           | ((unsigned long long)rstarts[lane] << 36)
+                                           | ((unsigned long long)(pos & 0xfffffu) << 44);
+                __hip_atomic_store(ents + (pos & (unsigned)as.cap_mask), e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                dirty[lane] = 0;
+            }
+            total = __popcll(bal);
+            if (lane == 0) sh[3] = total;
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        total = sh[3];
+        if (tid == 0 && total) atomicAdd(ht, (unsigned long long)total << 32);
+        __syncthreads();
+        return total;
+    };
+
+    for (;;) {
+        // ---- wait until the ring has room (and its slots have been read: published - completed
+        // stays well below the capacity)
+        unsigned h, c;
+        for (;;) {
+            if (tid == 0) {
+                sh[0] = (int)(unsigned)ald64(ht);
+                sh[1] = (int)ald32(completed);
+                int stop = ald32(as.status) != ASYNC_OK;
+                if (!stop && wall_clock64() - clock0 > as.timeout_ticks) { async_fail(as, ASYNC_ERR_TIMEOUT); stop = 1; }
+                if (!stop && (long long)t > as.max_entries) { async_fail(as, ASYNC_ERR_CAP); stop = 1; }
+                sh[2] = stop;
+            }
+            __syncthreads();
+            h = (unsigned)sh[0]; c = (unsigned)sh[1];
+            const int stop = sh[2];
+            __syncthreads();
+            if (stop) {         // give up: the workers see the status word and leave
+                if (tid == 0) atomicOr(ht, 1ull << 63);
+                return;
+            }
+            if ((int)(t - h) <= as.low && (int)(t - c) < as.cap_mask - 2048) break;
+            __builtin_amdgcn_s_sleep(32);
+        }
+        if (as.policy == 0 || base >= n) {      // a scan begins
+            if (base >= n) round++;
+            base = 0;
+            quiet = c == t;                     // nothing queued, nothing running: the scan sees a still picture
+            activity = 0;
+            const float gr = as.gate_r0 + as.gate_speed * (float)round;
+            gate_r2 = as.policy == 1 && as.gate_speed > 0.f ? gr * gr : 3.0e38f;
+            if (as.policy == 2) {
+                // window: a start's units are handed out up to `window` cells beyond the nearest unit
+                // the previous round met with anything to do (everything, if it met none)
+                __syncthreads();
+                if (tid < ASYNC_RING_STARTS) {
+                    const float m = __int_as_float(minact[tid]);
+                    const float gw = sqrtf(m) + as.window;
+                    gate2[tid] = m < 1.0e30f && as.window > 0.f ? gw * gw : 3.0e38f;
+                    minact[tid] = 0x7f000000;
+                }
+                __syncthreads();
+            }
+        }
+        for (; base < n; base += KSCAN * 256) {
+            if ((int)(t - h) >= as.high) break;
+            int ss[KSCAN], uu[KSCAN], dd[KSCAN];
+            unsigned w[KSCAN], planes[KSCAN];
+            unsigned *pw[KSCAN];
+            int open_any = 0;
+#pragma unroll
+            for (int k = 0; k < KSCAN; k++) {
+                const int idx = base + k * 256 + tid;
+                int4 it = make_int4(0, -1, 0, 0);
+                if (idx < n) it = list[idx];
+                if (__int_as_float(it.z) > (as.policy == 2 ? gate2[it.x >> 16] : gate_r2)) {   // behind the gate: not even looked at (the round ends
+                    if (it.y >= 0) activity = 1;        // where a whole step lies behind it); may hold bits
+                    it.y = -1;
+                } else if (it.y >= 0) {
+                    open_any = 1;
+                }
+                ss[k] = it.x; uu[k] = it.y; dd[k] = it.z;
+                pw[k] = reinterpret_cast<unsigned *>(flags0 + (long long)(it.x & 0xffff) * flags_stride + 2 * nflag) + max(it.y, 0);
+            }
+            if (!__syncthreads_or(open_any)) {          // (the list is in order of distance, nearly: what is
+                base = n;                               // missed now is met in a later round)
+                break;
+            }
+#pragma unroll
+            for (int k = 0; k < KSCAN; k++) w[k] = uu[k] >= 0 ? atomicOr(pw[k], 0u) : 0u;
+#pragma unroll
+            for (int k = 0; k < KSCAN; k++) {
+                planes[k] = 0;
+                if (w[k] != 0u) {
+                    activity = 1;
+                    if (as.policy == 2) atomicMin(&minact[ss[k] >> 16], dd[k]);
+                    // only the planner sets the busy bit: a word seen without it holds plane bits alone
+                    if (!(w[k] & ASYNC_BUSY)) planes[k] = atomicExch(pw[k], ASYNC_BUSY) & ~ASYNC_BUSY;
+                }
+            }
+            int rank[KSCAN];
+#pragma unroll
+            for (int k = 0; k < KSCAN; k++) {
+                const unsigned long long bal = __ballot(planes[k] != 0u);
+                rank[k] = __popcll(bal & ((1ull << lane) - 1ull));
+                if (lane == 0) cnt[k * STRIP_NS + wave] = __popcll(bal);
+            }
+            __syncthreads();
+            int total = 0, off[KSCAN];
+#pragma unroll
+            for (int k = 0; k < KSCAN; k++) {
+#pragma unroll
+                for (int ww = 0; ww < STRIP_NS; ww++) {
+                    if (ww == wave) off[k] = total;
+                    total += cnt[k * STRIP_NS + ww];
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < KSCAN; k++) {
+                unsigned long long relax = 0;
+                const int s = ss[k] & 0xffff;
+                if (planes[k] != 0u) {
+                    const unsigned pos = t + (unsigned)(off[k] + rank[k]);
+                    const unsigned long long e = (unsigned long long)planes[k] | ((unsigned long long)(unsigned)uu[k] << 16)
+                                               | ((unsigned long long)s << 36) | ((unsigned long long)(pos & 0xfffffu) << 44);
+                    __hip_atomic_store(ents + (pos & (unsigned)as.cap_mask), e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    atomicAdd(&dirty[ss[k] >> 16], 1);
+                    int u = uu[k];
+                    const int cs = u % cstrips;  u /= cstrips;
+                    const int bt = u % btiles;   u /= btiles;
+                    const int wb = min(min(STRIP_TB, L.n[1]), L.n[1] - bt * STRIP_TB), wc = max(min(STRIP_K, L.n[2] - cs * STRIP_K), 0);
+                    const bool two = NP > 1 && NP * u + 1 < L.n[0];
+                    int nent = 0;
+                    for (int p = 0; p < 2 * ra + NP; p++)
+                        if ((planes[k] >> p) & 1u) nent += pc.n[p][0] + (two ? pc.n[p][1] : 0);
+                    relax = (unsigned long long)(wb * wc) * (unsigned long long)nent;
+                }
+                // the starts' work counters: one pair of atomics per wavefront and start
+                unsigned long long rest = __ballot(planes[k] != 0u);
+                while (rest) {
+                    const int first = __builtin_ctzll(rest);
+                    const int s0 = __shfl(s, first);
+                    const bool mine = planes[k] != 0u && s == s0;
+                    const unsigned long long mm = __ballot(mine);
+                    unsigned long long sum = mine ? relax : 0ull;
+#pragma unroll
+                    for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+                    if (lane == first) {
+                        atomicAdd(starts[s0].work, sum);
+                        atomicAdd(starts[s0].work + 2, (unsigned long long)__popcll(mm));
+                    }
+                    rest &= ~mm;
+                }
+            }
+            // the entries are in memory before the tail says so
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (tid == 0 && total) atomicAdd(ht, (unsigned long long)total << 32);
+            t += (unsigned)total;
+        }
+        const bool whole = base >= n;
+        if (whole) activity = __syncthreads_or(activity);
+        if (whole && !activity && quiet) {
+            // the ring is at rest; the dead-edge cells once more if units ran since their last turn
+            const int sp = publish_specials(1);
+            if (sp == 0) {
+                // really at rest: the deferred bits (push_improved) become pend bits; none: done
+                int moved = 0;
+                for (int idx = tid; idx < n; idx += 256) {
+                    const int4 it = list[idx];
+                    if (it.y < 0) continue;
+                    unsigned *const df = reinterpret_cast<unsigned *>(flags0 + (long long)(it.x & 0xffff) * flags_stride) + it.y;
+                    const unsigned d = atomicExch(df, 0u);
+                    if (d) { atomicOr(df + 2 * nflag, d); moved = 1; }
+                }
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                if (!__syncthreads_or(moved)) {
+                    if (tid == 0) atomicOr(ht, 1ull << 63);
+                    return;
+                }
+            }
+            t += (unsigned)sp;
+        } else {
+            t += (unsigned)publish_specials(as.special_every);
+        }
+    }
+}
+
+// Worker, thread 0: the next ring entry (own ring first), or ASYNC_EXIT when every ring is done
+// or the solve has failed.  *ring: the ring the entry came from.
+__device__ __noinline__ unsigned long long async_claim(const AsyncSolve &as, const int home, int *ring, const long long clock0)
+{
+    for (unsigned spin = 0;; spin++) {
+        int ndone = 0;
+        for (int probe = 0; probe < as.nrings; probe++) {
+            const int q = (home + probe) % as.nrings;
+            unsigned long long *const ht = as.ctl + (size_t)q * ASYNC_CTL_STRIDE;
+            const unsigned long long x = ald64(ht);
+            const unsigned head = (unsigned)x, tail = (unsigned)(x >> 32) & 0x7fffffffu;
+            if ((int)(tail - head) > 0) {
+                const unsigned j = (unsigned)atomicAdd(ht, 1ull);
+                const unsigned long long *slot = as.entries + (size_t)q * (size_t)(as.cap_mask + 1) + (j & (unsigned)as.cap_mask);
+                for (unsigned spin2 = 0;; spin2++) {
+                    const unsigned long long e = ald64(slot);
+                    if ((unsigned)(e >> 44) == (j & 0xfffffu)) { *ring = q; return e; }
+                    // not published (yet): somebody else was faster and position j lies beyond the tail
+                    const unsigned long long y = ald64(ht);
+                    if ((y >> 63) && (int)(j - ((unsigned)(y >> 32) & 0x7fffffffu)) >= 0) break;   // ... and never will be
+                    if ((spin2 & 63u) == 63u) {
+                        if (ald32(as.status) != ASYNC_OK) return ASYNC_EXIT;
+                        if (wall_clock64() - clock0 > as.timeout_ticks) { async_fail(as, ASYNC_ERR_TIMEOUT); return ASYNC_EXIT; }
+                    }
+                    __builtin_amdgcn_s_sleep(8);
+                }
+            } else if (x >> 63) {
+                ndone++;
+            }
+        }
+        if (ndone == as.nrings) return ASYNC_EXIT;
+        if ((spin & 15u) == 15u) {
+            if (ald32(as.status) != ASYNC_OK) return ASYNC_EXIT;
+            if (wall_clock64() - clock0 > as.timeout_ticks) { async_fail(as, ASYNC_ERR_TIMEOUT); return ASYNC_EXIT; }
+        }
+        __builtin_amdgcn_s_sleep(24);
+    }
+}
+
+template <int K, int NP, bool ASYNC>
 __global__ void __launch_bounds__(STRIP_TB *STRIP_NS, TTSWEEP_WGS_PER_CU)
 sweep_units_kernel(DevLayout L, const float *__restrict__ v, const StartDesc *__restrict__ starts,
                    const int4 *__restrict__ lists, int list_cap, int nlists, int *__restrict__ ctrl,
                    int *__restrict__ changed, const StripItem *__restrict__ items, StripPlan plan,
-                   int btiles, int cstrips, UnitPassTail tail)
+                   int btiles, int cstrips, UnitPassTail tail, AsyncSolve as, PlaneCounts pc,
+                   int *__restrict__ flags0, long long flags_stride)
 {
     constexpr int NS = STRIP_NS;
     constexpr int W = K + 2 * STRIP_CF;
@@ -1055,34 +1407,77 @@ sweep_units_kernel(DevLayout L, const float *__restrict__ v, const StartDesc *__
     // the queue lengths are final when this kernel starts (the planner wrote them): read them
     // once - an empty queue then costs no memory round trip, and an empty pass none at all
     int *qcount = head + 2;                         // [0 .. nlists)
-    if (tid < UNITQ_LISTS) qcount[tid] = tid < nlists ? ctrl[tid] : 0;
+    if (!ASYNC && tid < UNITQ_LISTS) qcount[tid] = tid < nlists ? ctrl[tid] : 0;
     __syncthreads();
 
-    // ---- the dead-edge cells of the active starts, one wave per cell
-    for (int w = blockIdx.x * NS + wave; w < tail.nactive * tail.max_box_cells; w += gridDim.x * NS) {
-        const int s = tail.active[w / tail.max_box_cells];
-        const StartDesc sd = starts[s];
-        relax_special_cell(L, v, sd, s, w % tail.max_box_cells, changed, tail.entries, tail.nentries,
-                           plan.ra, NP, lane);
+    if (ASYNC) {
+        // one launch per solve: the first workgroups plan (one ring each), the others work
+        if ((int)blockIdx.x < as.nrings) {
+            async_planner<NP>(L, starts, as, (int)blockIdx.x, btiles, cstrips, plan.ra, pc, flags0, flags_stride,
+                              reinterpret_cast<int *>(smem) + STRIP_LDS_HEAD);
+            return;
+        }
+    } else {
+        // ---- the dead-edge cells of the active starts, one wave per cell
+        for (int w = blockIdx.x * NS + wave; w < tail.nactive * tail.max_box_cells; w += gridDim.x * NS) {
+            const int s = tail.active[w / tail.max_box_cells];
+            const StartDesc sd = starts[s];
+            relax_special_cell(L, v, sd, s, w % tail.max_box_cells, changed, tail.entries, tail.nentries,
+                               plan.ra, NP, lane, tail.defer_margin);
+        }
     }
 
     PROF_T(t_k0);
     // own queue first: the one of the XCD this workgroup runs on (speed only: a start's
     // volumes then stay in one L2; any workgroup may drain any queue)
-    const int home = (int)(xcc_id() % (unsigned)nlists);
+    const int home = (int)(xcc_id() % (unsigned)(ASYNC ? as.nrings : nlists));
     int probe = 0, it = 0;
     // The index of the unit after the current one is asked for while the current one is being
     // relaxed (`ahead`, held by thread 0); -1: nothing asked for yet.
     int ahead = -1;
     int flagged = -1;           // (lane 0 of a wave) the start whose "improved" bit this wave has set
+    const long long async_clock0 = ASYNC ? wall_clock64() : 0;
 #ifdef TTSWEEP_PROFILE
     unsigned long long prof_acc[7] = {};
 #endif
-    while (probe < nlists) {
+    while (ASYNC || probe < nlists) {
         // ---- take the next unit of queue q (every wave leaves through the same exit:
         // all queues exhausted)
         PROF_T(t_top);
-        const int q = (home + probe) % nlists;
+        int s, my_unit, q;
+        unsigned my_planes;
+        if (ASYNC) {
+            // a ring entry; what it stands for was released by its producers before the planner
+            // could see their bits: acquire before anything of it is loaded
+            if (tid == 0) {
+                int ring = 0;
+                const unsigned long long e = async_claim(as, home, &ring, async_clock0);
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                head[0] = (int)(unsigned)e;
+                head[1] = (int)(unsigned)(e >> 32);
+                head[2] = ring;
+            }
+            __syncthreads();
+            const unsigned e_lo = (unsigned)__builtin_amdgcn_readfirstlane(head[0]);
+            const unsigned e_hi = (unsigned)__builtin_amdgcn_readfirstlane(head[1]);
+            q = __builtin_amdgcn_readfirstlane(head[2]);
+            if ((e_lo & e_hi) == 0xffffffffu) break;        // ASYNC_EXIT
+            my_planes = e_lo & 0xffffu;
+            my_unit = (int)((e_lo >> 16) | ((e_hi & 0xfu) << 16));
+            s = (int)((e_hi >> 4) & 0xffu);
+            if ((unsigned)my_unit == ASYNC_UNIT_SPECIAL) {
+                // the dead-edge cells of start s, one wave per cell
+                const StartDesc sd = starts[s];
+                for (int cell = wave; cell < tail.max_box_cells; cell += NS)
+                    relax_special_cell<true>(L, v, sd, s, cell, changed, tail.entries, tail.nentries, plan.ra, NP, lane, tail.defer_margin);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();
+                if (tid == 0) atomicAdd(reinterpret_cast<unsigned *>(as.ctl + (size_t)q * ASYNC_CTL_STRIDE + 16), 1u);
+                continue;
+            }
+        } else {
+        q = (home + probe) % nlists;
         const int n = __builtin_amdgcn_readfirstlane(qcount[q]);
         if (n == 0) { probe++; continue; }          // (uniform: nothing was asked of an empty queue)
         if (tid == 0) {
@@ -1096,14 +1491,15 @@ sweep_units_kernel(DevLayout L, const float *__restrict__ v, const StartDesc *__
         ahead = -1;
         if (j >= n) { probe++; continue; }
         if (tid == 0) ahead = atomicAdd(&ctrl[UNITQ_LISTS + q], 1);     // (arrives during the unit)
+        const const_entry_ptr entry = (const_entry_ptr)(lists + ((size_t)q * list_cap + j));
+        s = entry->s;
+        my_unit = entry->unit;
+        my_planes = (unsigned)entry->planes;
+        }
         PROF_T(t_fetch);
 #ifdef TTSWEEP_PROFILE
         long long p_wait = 0, p_stage = 0, p_comp = 0;
 #endif
-        const const_entry_ptr entry = (const_entry_ptr)(lists + ((size_t)q * list_cap + j));
-        const int s = entry->s;
-        const int my_unit = entry->unit;
-        const unsigned my_planes = (unsigned)entry->planes;
         int u = my_unit;
         const int cs = u % cstrips;  u /= cstrips;
         const int bt = u % btiles;   u /= btiles;
@@ -1267,12 +1663,43 @@ sweep_units_kernel(DevLayout L, const float *__restrict__ v, const StartDesc *__
         }
 #pragma unroll
         for (int w = 32; w >= 1; w >>= 1) improved |= __shfl_xor(improved, w);
+        if (ASYNC) {
+            // every wave's stores have left it; one release for the workgroup; then the bits
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            const int any_improved = __syncthreads_or(improved);
+#ifdef TTSWEEP_ASYNC_STATS
+            // (tuning aid) units / staged planes relaxed, and those of them that improved nothing at all
+            if (tid == 0) {
+                atomicAdd(as.status + 4, 1u);
+                atomicAdd(as.status + 5, (unsigned)__popc(my_planes));
+                if (!any_improved) { atomicAdd(as.status + 6, 1u); atomicAdd(as.status + 7, (unsigned)__popc(my_planes)); }
+            }
+#endif
+            if (any_improved) {
+                if (tid == 0) {
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                }
+                __syncthreads();
+            }
+        }
         if (improved) {         // (wave-uniform) the units that stage this plane have to look again
+            const DeferRule rule{sdp->sa, sdp->sb, sdp->sc, tail.defer_margin};
             push_improved<NP>(L, plan.ra, btiles, cstrips, reinterpret_cast<unsigned *>(tile_flags + 2 * nflag),
-                              a, bt, cs, improved, lane);
+                              a, bt, cs, improved, lane, rule, reinterpret_cast<unsigned *>(tile_flags));
             // (the start's word: once per wave, start and pass - its few words are a hot spot)
             if (lane == 0 && s != flagged) atomicOr(&changed[s], CHANGED_IMPROVED);
             flagged = s;
+        }
+        if (ASYNC) {
+            // the bits are out: the unit may be planned again, and only then does it count as completed
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (tid == 0) {
+                atomicAnd(reinterpret_cast<unsigned *>(tile_flags + 2 * nflag) + my_unit, ~ASYNC_BUSY);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                atomicAdd(reinterpret_cast<unsigned *>(as.ctl + (size_t)q * ASYNC_CTL_STRIDE + 16), 1u);
+            }
         }
 #ifdef TTSWEEP_PROFILE
         {   // (summed per workgroup, added to the totals once at its end: seven atomics per unit
@@ -1295,6 +1722,7 @@ sweep_units_kernel(DevLayout L, const float *__restrict__ v, const StartDesc *__
     }
 #endif
 
+    if (ASYNC) return;          // (the host reads the words after the one launch)
     // ---- the last workgroup to leave closes the pass: it hands the "changed" words to the
     // host (pinned memory) and clears the queue counters and the next pass's words, so a pass
     // needs no memset / copy commands around its two kernels.  All its threads take part (one
@@ -1357,7 +1785,7 @@ hipError_t launch_sweep_units(const DevLayout &L, const float *v, const StartDes
         return hipErrorInvalidValue;                    // (the last workgroup closes the pass)
     if (plan.np < 1 || plan.np > STRIP_PLANES) return hipErrorInvalidValue;
     const int btiles = strip_btiles(L);
-    auto kern = plan.np == 1 ? sweep_units_kernel<STRIP_K, 1> : sweep_units_kernel<STRIP_K, 2>;
+    auto kern = plan.np == 1 ? sweep_units_kernel<STRIP_K, 1, false> : sweep_units_kernel<STRIP_K, 2, false>;
     const size_t lds = units_lds_bytes(plan, L.n[1]);
     if (lds > 48 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
@@ -1365,7 +1793,32 @@ hipError_t launch_sweep_units(const DevLayout &L, const float *v, const StartDes
         if (e != hipSuccess) return e;
     }
     hipLaunchKernelGGL(kern, dim3((unsigned)nblocks), dim3(STRIP_TB, STRIP_NS), lds, st, L, v, starts,
-                       lists, list_cap, nlists, ctrl, changed, items, plan, btiles, strip_cstrips(L), tail);
+                       lists, list_cap, nlists, ctrl, changed, items, plan, btiles, strip_cstrips(L), tail,
+                       AsyncSolve{}, PlaneCounts{}, (int *)nullptr, 0ll);
+    return hipGetLastError();
+}
+
+hipError_t launch_solve_units(const DevLayout &L, const float *v, const StartDesc *starts, int nblocks,
+                              int *changed, const StripItem *items, const StripPlan &plan,
+                              const UnitPassTail &tail, const AsyncSolve &as, int *flags0, long long flags_stride,
+                              hipStream_t st)
+{
+    if (as.nrings < 1 || as.nrings > ASYNC_MAX_RINGS || nblocks <= as.nrings) return hipErrorInvalidValue;
+    if (plan.np < 1 || plan.np > STRIP_PLANES) return hipErrorInvalidValue;
+    const int btiles = strip_btiles(L);
+    auto kern = plan.np == 1 ? sweep_units_kernel<STRIP_K, 1, true> : sweep_units_kernel<STRIP_K, 2, true>;
+    const size_t lds = units_lds_bytes(plan, L.n[1]);
+    if (lds > 48 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+    }
+    PlaneCounts pc;
+    for (int p = 0; p < STRIP_STAGED; p++)
+        for (int j = 0; j < STRIP_PLANES; j++) pc.n[p][j] = p < plan.nstaged ? plan.nent[p][j] : 0;
+    hipLaunchKernelGGL(kern, dim3((unsigned)nblocks), dim3(STRIP_TB, STRIP_NS), lds, st, L, v, starts,
+                       (const int4 *)nullptr, 0, as.nrings, (int *)nullptr, changed, items, plan, btiles,
+                       strip_cstrips(L), tail, as, pc, flags0, flags_stride);
     return hipGetLastError();
 }
 

@@ -368,19 +368,20 @@ int upload_star(ttsweep_ctx *ctx)
 
 // Activity words of one start: two parities of unit flags, the held-back plane bits and the
 // number of source units (see plan_pass_kernel).
-size_t flag_words(const DevLayout &L)
+size_t flag_words(const DevLayout &L, int kernel)
 {
-    const size_t strip = 3 * (size_t)std::max(strip_units(L, 1), 1) + 4;      // (one-plane units: the larger grid)
+    const size_t strip = kernel == TTSWEEP_KERNEL_STRIP
+        ? 3 * (size_t)std::max(strip_units(L, 1), 1) + 4 : 0;      // (one-plane units: the larger grid)
     const size_t tile = 2 * (size_t)tile_count(L.n[0], TILE_X) * tile_count(L.n[1], TILE_Y) * tile_count(L.n[2], TILE_Z);
-    return (std::max(strip, tile) + 1) & ~(size_t)1;       // (even: the TILE kernel views them as int2)
+    return (std::max(strip, tile) + 31) & ~(size_t)31;     // (even: the TILE kernel views them as int2; whole lines)
 }
 
 // Device bytes ensure_capacity allocates per start (ttsweep_solve sizes its batches with it).
 size_t per_start_device_bytes(const ttsweep_ctx *ctx)
 {
     size_t b = (size_t)ctx->L.cells * sizeof(float)                 // padded travel-time volume
-             + flag_words(ctx->L) * sizeof(int)                     // activity words
-             + sizeof(StartDesc) + (1 + PASS_SLOTS) * sizeof(int) + 3 * sizeof(unsigned long long);
+             + flag_words(ctx->L, ctx->kernel) * sizeof(int)                     // activity words
+             + sizeof(StartDesc) + (2 + PASS_SLOTS) * sizeof(int) + 3 * sizeof(unsigned long long);
     if (ctx->kernel == TTSWEEP_KERNEL_TILE)
         b += (size_t)tile_face_cells(ctx->L, ctx->tile_fz) * sizeof(float);     // z faces
     if (ctx->kernel == TTSWEEP_KERNEL_STRIP)                        // static work list + unit queues
@@ -411,12 +412,12 @@ int ensure_capacity(ttsweep_ctx *ctx, int nstart)
     HIPCHK(hipMalloc((void **)&ctx->d_T, (size_t)nstart * ctx->L.cells * sizeof(float)));
     HIPCHK(hipMalloc((void **)&ctx->d_starts, nstart * sizeof(StartDesc)));
     HIPCHK(hipMalloc((void **)&ctx->d_active, nstart * sizeof(int)));
-    HIPCHK(hipMalloc((void **)&ctx->d_changed, PASS_SLOTS * nstart * sizeof(int)));
+    HIPCHK(hipMalloc((void **)&ctx->d_changed, (PASS_SLOTS + 1) * nstart * sizeof(int)));     // (+ 1: the flush of deferred bits)
     HIPCHK(hipHostMalloc((void **)&ctx->h_starts, nstart * sizeof(StartDesc)));
     HIPCHK(hipHostMalloc((void **)&ctx->h_active, nstart * sizeof(int)));
-    HIPCHK(hipHostMalloc((void **)&ctx->h_changed, PASS_SLOTS * nstart * sizeof(int)));
+    HIPCHK(hipHostMalloc((void **)&ctx->h_changed, (PASS_SLOTS + 1) * nstart * sizeof(int)));
     HIPCHK(hipMalloc((void **)&ctx->d_tile_flags,
-                     (size_t)nstart * flag_words(ctx->L) * sizeof(int)));
+                     (size_t)nstart * flag_words(ctx->L, ctx->kernel) * sizeof(int)));
     HIPCHK(hipMalloc((void **)&ctx->d_work, 3 * nstart * sizeof(unsigned long long)));
     HIPCHK(hipHostMalloc((void **)&ctx->h_work, 3 * nstart * sizeof(unsigned long long)));
     if (ctx->kernel == TTSWEEP_KERNEL_TILE)
@@ -436,6 +437,19 @@ int ensure_capacity(ttsweep_ctx *ctx, int nstart)
 // it and the start have finished their update of this pass: fresh travel times then cross
 // several units in ONE pass instead of one unit per pass.  Correctness never depends on
 // this order.
+int ensure_unit_grid(ttsweep_ctx *ctx)
+{
+    if (ctx->unitq_blocks == 0) {
+        hipDeviceProp_t prop;
+        HIPCHK(hipGetDeviceProperties(&prop, ctx->device));
+        const int wgs = units_wgs_per_cu() * std::max(prop.multiProcessorCount, 1);     // 2 workgroups (8 waves) per CU:
+            // measured optimum - a third one adds no throughput, lengthens every unit and lets
+            // fewer units see their neighbours' updates of the same pass
+        ctx->unitq_blocks = ((wgs + ctx->nlists - 1) / ctx->nlists) * ctx->nlists;
+    }
+    return 0;
+}
+
 int build_worklist(ttsweep_ctx *ctx, int nactive)
 {
     const auto t_begin = std::chrono::steady_clock::now();
@@ -484,14 +498,7 @@ int build_worklist(ttsweep_ctx *ctx, int nactive)
         ctx->unitq_cap = longest;
     }
     if (!ctx->d_unitq_ctrl) HIPCHK(hipMalloc((void **)&ctx->d_unitq_ctrl, (UNITQ_CTRL_WORDS + 1) * sizeof(int)));
-    if (ctx->unitq_blocks == 0) {
-        hipDeviceProp_t prop;
-        HIPCHK(hipGetDeviceProperties(&prop, ctx->device));
-        const int wgs = units_wgs_per_cu() * std::max(prop.multiProcessorCount, 1);     // 2 workgroups (8 waves) per CU:
-            // measured optimum - a third one adds no throughput, lengthens every unit and lets
-            // fewer units see their neighbours' updates of the same pass
-        ctx->unitq_blocks = ((wgs + ctx->nlists - 1) / ctx->nlists) * ctx->nlists;
-    }
+    if (ensure_unit_grid(ctx)) return -1;
 #ifdef TTSWEEP_DEBUG_ENV
     if (getenv("TTSWEEP_TRACE"))
         fprintf(stderr, "ttsweep work list for %d starts: %.0f us\n", nactive,
