@@ -133,6 +133,9 @@ def workload_args(args):
             "--nstarts", str(args.nstarts), "--kernel", str(args.kernel)] + \
         (["--gate-speed", str(args.gate_speed)] if args.gate_speed is not None else []) + \
         (["--pair-min-starts", str(args.pair_min_starts)] if args.pair_min_starts is not None else []) + \
+        (["--async-mode", str(args.async_mode)] if args.async_mode is not None else []) + \
+        (["--async-gate", str(args.async_gate)] if args.async_gate is not None else []) + \
+        (["--defer-margin", str(args.defer_margin)] if args.defer_margin is not None else []) + \
         (["--prepass", str(args.prepass)] if args.prepass else []) + \
         (["--lib", args.lib] if args.lib else [])
 
@@ -242,7 +245,7 @@ def hbm_regime_wanted(args):
 def hbm_regime_args(args):
     a = argparse.Namespace(**vars(args))
     a.grid, a.star, a.starts, a.nstarts = (HBM_REGIME[k] for k in ("grid", "star", "starts", "nstarts"))
-    a.gate_speed = a.pair_min_starts = None
+    a.gate_speed = a.pair_min_starts = a.async_mode = a.async_gate = a.defer_margin = None
     a.prepass = 0
     return a
 
@@ -326,6 +329,11 @@ def main():
     ap.add_argument("--gate-speed", type=float, default=None, help="schedule knob of the STRIP kernel (cells/pass)")
     ap.add_argument("--pair-min-starts", type=int, default=None,
                     help="schedule knob of the STRIP kernel: units of two planes from this many starts on")
+    ap.add_argument("--async-mode", type=int, default=None, choices=[-1, 0, 1],
+                    help="schedule knob of the STRIP kernel: 1 one launch per solve, 0 a launch pair per pass, -1 library default")
+    ap.add_argument("--async-gate", type=float, default=None, help="schedule knob: cells per round by which the gate of a one-launch solve opens")
+    ap.add_argument("--defer-margin", type=float, default=None,
+                    help="schedule knob: improvements are told at once only to units not nearer to the start by more than this (cells)")
     ap.add_argument("--prepass", type=int, default=0,
                     help="schedule knob: relax the first N star entries to convergence first (TTSWEEP_OPT_PREPASS_ENTRIES)")
     ap.add_argument("--lib", default=None, help="another build of libttsweep.so (A/B builds, tools/exp)")
@@ -411,6 +419,12 @@ def main():
         sol.set_option(P.OPT_GATE_SPEED_MILLI, int(round(args.gate_speed * 1000)))
     if args.pair_min_starts is not None:
         sol.set_option(P.OPT_PAIR_MIN_STARTS, args.pair_min_starts)
+    if args.async_mode is not None:
+        sol.set_option(P.OPT_ASYNC, args.async_mode)
+    if args.async_gate is not None:
+        sol.set_option(P.OPT_ASYNC_GATE_MILLI, int(round(args.async_gate * 1000)))
+    if args.defer_margin is not None:
+        sol.set_option(P.OPT_DEFER_MARGIN_MILLI, int(round(args.defer_margin * 1000)))
     sol.set_velocity(v_dev)
     if args.prepass:
         sol.set_option(P.OPT_PREPASS_ENTRIES, args.prepass)
@@ -481,7 +495,8 @@ def main():
         flops = FLOPS_PER_RELAX * relax
         gbs = alg_bytes / kern_s / 1e9 if kern_s > 0 else 0.0
         tfl = flops / kern_s / 1e12 if kern_s > 0 else 0.0
-        kname = {1: "sweep_cell_kernel", 2: "plan_pass_kernel + sweep_units_kernel (one pass)",
+        kname = {1: "sweep_cell_kernel", 2: "plan_pass_kernel + sweep_units_kernel (one pass)" if st["launches"] > 1 else
+                 "sweep_units_kernel<16, np, true> (ONE launch per solve: ring planners + workers, convergence detected on the device)",
                  3: "tile_plan_kernel + tile_six_kernel / tile_sweep_kernel (one tile hyperplane of an ordering sweep)"}[st["kernel_variant"]]
         common = {"kernel": kname, "launches": int(launches), "avg_launch_ms": st["sweep_kernel_ms"] / launches,
                   "algorithmic_bytes_per_launch": alg_bytes / launches,

@@ -29,7 +29,7 @@ for cfg in sys.argv[2:]:
         if high: sol.set_option(P.OPT_ASYNC_HIGH, high)
         if special: sol.set_option(P.OPT_ASYNC_SPECIAL, special)
         sol.set_option(P.OPT_ASYNC_POLICY, policy)
-        if gate >= 0: sol.set_option(P.OPT_ASYNC_WINDOW_MILLI if policy == 2 else P.OPT_GATE_SPEED_MILLI, gate)
+        if gate >= 0: sol.set_option(P.OPT_ASYNC_WINDOW_MILLI if policy == 2 else (P.OPT_ASYNC_GATE_MILLI if mode == 1 else P.OPT_GATE_SPEED_MILLI), gate)
         sol.set_option(P.OPT_DEFER_MARGIN_MILLI, margin)
         best = None
         for rep in range(3):

@@ -97,12 +97,13 @@ struct ttsweep_ctx {
     double gate_r0 = 0.0;
     // STRIP: bits for units nearer to the start than the improved cells by more than this many cells are
     // deferred until the start is otherwise at rest (push_improved); < -1e30: off
-    float defer_margin = 0.f;
+    float defer_margin = 1.f;
     // STRIP, one launch per solve (AsyncSolve, ttsweep_dev.h)
     int async_mode = -1;                    // TTSWEEP_OPT_ASYNC
     int async_low = 0, async_high = 0;      // 0: defaults (solve_async_strip)
     int async_special_every = 128;
-    int async_policy = 2;                   // TTSWEEP_OPT_ASYNC_POLICY
+    int async_policy = 1;                   // TTSWEEP_OPT_ASYNC_POLICY
+    float async_gate_speed = 0.75f;         // cells per round (policy 1; TTSWEEP_OPT_ASYNC_GATE_MILLI)
     float async_window = 16.f;              // TTSWEEP_OPT_ASYNC_WINDOW_MILLI
     int4 *d_async_list = nullptr;           // the rings' unit lists
     size_t async_list_cap = 0;

@@ -184,6 +184,7 @@ struct AsyncSolve {
                                     //    units that the previous round found with anything to do
     float gate_r0, gate_speed;      // policy 1; speed <= 0: no gate
     float window;                   // policy 2; <= 0: no gate
+    int scan_slack;                 // list entries in front of the first unit with anything to do that a round still scans
     int ring_off[ASYNC_MAX_RINGS], ring_len[ASYNC_MAX_RINGS];
     int ring_start_off[ASYNC_MAX_RINGS + 1];    // ring r serves starts ring_starts[ring_start_off[r] .. [r + 1])
     const int *ring_starts;

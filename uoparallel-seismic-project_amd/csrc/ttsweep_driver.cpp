@@ -186,7 +186,7 @@ static bool use_async(const ttsweep_ctx *ctx, int nstart)
 {
     if (ctx->kernel != TTSWEEP_KERNEL_STRIP || ctx->async_mode == 0) return false;
     if (nstart > ASYNC_MAX_STARTS || strip_units(ctx->L, ctx->np) >= (int)ASYNC_UNIT_SPECIAL) return false;
-    return ctx->async_mode == 1;
+    return true;        // (-1: wherever it can run; 1: the same)
 }
 
 // The whole driver loop as one launch: the rings' lists (every unit of a ring's starts, nearest
@@ -210,7 +210,7 @@ static int solve_async_strip(ttsweep_ctx *ctx, int nstart, bool single_source, s
     // lists
     as.policy = ctx->async_policy;
     as.gate_r0 = (float)ctx->gate_r0;
-    as.gate_speed = single_source ? (float)ctx->gate_speed : 0.f;      // (the gate is for solves that grow from one unit)
+    as.gate_speed = single_source && ctx->gate_speed > 0 ? ctx->async_gate_speed : 0.f;      // (the gate is for solves that grow from one unit)
     as.window = single_source ? ctx->async_window : 0.f;
     const int btiles = strip_btiles(ctx->L), cstrips = strip_cstrips(ctx->L);
     auto gate_d2 = [&](int s, int unit) {       // squared distance from the start to the unit's cells (plan_pass_kernel)
@@ -242,6 +242,7 @@ static int solve_async_strip(ttsweep_ctx *ctx, int nstart, bool single_source, s
         as.ring_len[r] = (int)flat.size() - as.ring_off[r];
     }
     as.ring_start_off[as.nrings] = (int)ring_starts.size();
+    as.scan_slack = 16384 * ((nstart + as.nrings - 1) / as.nrings);
     if (flat.size() > ctx->async_list_cap) {
         if (ctx->d_async_list) HIPCHK(hipFree(ctx->d_async_list));
         ctx->d_async_list = nullptr;

@@ -1119,6 +1119,7 @@ __device__ __noinline__ void async_planner(const DevLayout &L, const StartDesc *
     if (tid < ASYNC_RING_STARTS) {
         dirty[tid] = tid < ns ? 1 : 0;          // (the first thing a ring does: its starts' dead-edge cells)
         minact[tid] = 0;                        // (the first round: the window around the start itself)
+        if (tid == 0) sh[4] = 0x7fffffff;
         gate2[tid] = 3.0e38f;
     }
     __syncthreads();
@@ -1127,7 +1128,7 @@ __device__ __noinline__ void async_planner(const DevLayout &L, const StartDesc *
     // state of the scan in progress (uniform but `activity`): where it continues, which round it belongs to,
     // whether the ring was at rest when it began, whether it met a word that was not zero
     int base = n, round = -1, activity = 0;
-    bool quiet = false;
+    bool quiet = false, from_zero = true;
     float gate_r2 = 3.0e38f;
 
     // publishes the dead-edge entries of the ring's starts whose counter has reached `threshold`
@@ -1181,7 +1182,18 @@ __device__ __noinline__ void async_planner(const DevLayout &L, const StartDesc *
         }
         if (as.policy == 0 || base >= n) {      // a scan begins
             if (base >= n) round++;
+            // Where: at the first list position the previous round met with anything to do, less a
+            // margin (what lies in front of it is at rest, but for a stray bit a neighbour may have
+            // set since) - on long lists most of a scan would otherwise cross units that have long
+            // converged; from the very beginning every 16th round, after a round that met nothing,
+            // and therefore always before the ring is declared at rest.
+            __syncthreads();
+            const int fa = sh[4];
+            __syncthreads();
+            if (tid == 0) sh[4] = 0x7fffffff;
             base = 0;
+            if (as.policy != 0 && fa < n && (round & 15) != 0) base = max(fa - as.scan_slack, 0) / (KSCAN * 256) * (KSCAN * 256);
+            from_zero = base == 0;
             quiet = c == t;                     // nothing queued, nothing running: the scan sees a still picture
             activity = 0;
             const float gr = as.gate_r0 + as.gate_speed * (float)round;
@@ -1225,6 +1237,12 @@ __device__ __noinline__ void async_planner(const DevLayout &L, const StartDesc *
             }
 #pragma unroll
             for (int k = 0; k < KSCAN; k++) w[k] = uu[k] >= 0 ? atomicOr(pw[k], 0u) : 0u;
+            {
+                bool anyw = false;
+#pragma unroll
+                for (int k = 0; k < KSCAN; k++) anyw |= w[k] != 0u;
+                if (__ballot(anyw) != 0ull && lane == 0) atomicMin(&sh[4], base);
+            }
 #pragma unroll
             for (int k = 0; k < KSCAN; k++) {
                 planes[k] = 0;
@@ -1297,7 +1315,7 @@ __device__ __noinline__ void async_planner(const DevLayout &L, const StartDesc *
         }
         const bool whole = base >= n;
         if (whole) activity = __syncthreads_or(activity);
-        if (whole && !activity && quiet) {
+        if (whole && !activity && quiet && from_zero) {
             // the ring is at rest; the dead-edge cells once more if units ran since their last turn
             const int sp = publish_specials(1);
             if (sp == 0) {
@@ -1666,16 +1684,7 @@ sweep_units_kernel(DevLayout L, const float *__restrict__ v, const StartDesc *__
         if (ASYNC) {
             // every wave's stores have left it; one release for the workgroup; then the bits
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            const int any_improved = __syncthreads_or(improved);
-#ifdef TTSWEEP_ASYNC_STATS
-            // (tuning aid) units / staged planes relaxed, and those of them that improved nothing at all
-            if (tid == 0) {
-                atomicAdd(as.status + 4, 1u);
-                atomicAdd(as.status + 5, (unsigned)__popc(my_planes));
-                if (!any_improved) { atomicAdd(as.status + 6, 1u); atomicAdd(as.status + 7, (unsigned)__popc(my_planes)); }
-            }
-#endif
-            if (any_improved) {
+            if (__syncthreads_or(improved)) {
                 if (tid == 0) {
                     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1693,11 +1702,11 @@ sweep_units_kernel(DevLayout L, const float *__restrict__ v, const StartDesc *__
         }
         if (ASYNC) {
             // the bits are out: the unit may be planned again, and only then does it count as completed
+            // (a busy word counts as activity for the planner: clearing and counting need no order)
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
             if (tid == 0) {
                 atomicAnd(reinterpret_cast<unsigned *>(tile_flags + 2 * nflag) + my_unit, ~ASYNC_BUSY);
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 atomicAdd(reinterpret_cast<unsigned *>(as.ctl + (size_t)q * ASYNC_CTL_STRIDE + 16), 1u);
             }
         }
