@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define TTSWEEP_ABI_VERSION 3
+#define TTSWEEP_ABI_VERSION 4
 
 /* Forward-star entry: same layout as `struct FS`
  * (serial_new/sweep-tt-multistart.c:46-49).  d must already hold

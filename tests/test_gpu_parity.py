@@ -24,13 +24,15 @@ def P(pkg):
 
 
 def gpu_converge(P, v, fs, starts, starstart=0, starstop=None, tts=None, kernel=None):
-    """kernel: 1 CELL, 2 STRIP (its own choice of unit size), 3 TILE; 21 / 22: STRIP with units
-    of one / two planes whatever the number of starts (latency / throughput mode)."""
+    """kernel: 1 CELL, 2 STRIP (its own choice of unit size and driver), 3 TILE; 21 / 22: STRIP with
+    units of one / two planes whatever the number of starts (latency / throughput mode), the solve as
+    ONE launch (ring planners + workers); 23 / 24: the same units, a launch pair per pass."""
     starts = np.asarray(starts, dtype=np.int32).reshape(-1, 3)
     with P.TravelTimeSolver(v.shape, fs, starstart, starstop) as sol:
-        if kernel in (21, 22):
+        if kernel in (21, 22, 23, 24):
             sol.set_option(P.OPT_KERNEL, 2)
-            sol.set_option(P.OPT_PAIR_MIN_STARTS, 1 << 20 if kernel == 21 else 0)
+            sol.set_option(P.OPT_PAIR_MIN_STARTS, 1 << 20 if kernel in (21, 23) else 0)
+            sol.set_option(P.OPT_ASYNC, 1 if kernel in (21, 22) else 0)
         elif kernel is not None:
             sol.set_option(P.OPT_KERNEL, kernel)
         sol.set_velocity(v)
@@ -44,7 +46,8 @@ def gpu_converge(P, v, fs, starts, starstart=0, starstop=None, tts=None, kernel=
         return tts, rc, sol.stats()
 
 
-KERNELS = [pytest.param(1, id="cell"), pytest.param(21, id="strip1"), pytest.param(22, id="strip2")]
+KERNELS = [pytest.param(1, id="cell"), pytest.param(21, id="strip1"), pytest.param(22, id="strip2"),
+           pytest.param(23, id="strip1-passes"), pytest.param(24, id="strip2-passes")]
 
 
 def tile_supports(offs):
@@ -642,6 +645,64 @@ def test_result_does_not_depend_on_the_gate(P, golden24, speed, r0):
         assert sol.solve(starts, tts) == 1 and sol.stats()["kernel_variant"] == 2
     for k, tt in zip(keys, tts):
         assert_bit_equal(tt, golden24.z[f"tt_{k}"], f"{k} gate {speed}/{r0}")
+
+
+SCHEDULES = [
+    # (one launch per solve?, {option: value}) - every knob that decides WHEN a unit is relaxed or told
+    (1, {}),
+    (1, {"OPT_ASYNC_POLICY": 0}),
+    (1, {"OPT_ASYNC_POLICY": 0, "OPT_ASYNC_LOW": 1, "OPT_ASYNC_HIGH": 2}),
+    (1, {"OPT_ASYNC_POLICY": 1, "OPT_ASYNC_GATE_MILLI": 100, "OPT_ASYNC_LOW": 200, "OPT_ASYNC_HIGH": 4000}),
+    (1, {"OPT_ASYNC_POLICY": 1, "OPT_ASYNC_GATE_MILLI": 20000, "OPT_ASYNC_SPECIAL": 1}),
+    (1, {"OPT_ASYNC_POLICY": 2, "OPT_ASYNC_WINDOW_MILLI": 3000, "OPT_ASYNC_SPECIAL": 1 << 20}),
+    (1, {"OPT_ASYNC_POLICY": 2, "OPT_ASYNC_WINDOW_MILLI": 0}),
+    (1, {"OPT_DEFER_MARGIN_MILLI": -1000000000}),
+    (1, {"OPT_DEFER_MARGIN_MILLI": -4000}),
+    (1, {"OPT_DEFER_MARGIN_MILLI": 0, "OPT_GATE_SPEED_MILLI": 0}),
+    (1, {"OPT_DEFER_MARGIN_MILLI": 6000, "OPT_PAIR_MIN_STARTS": 0}),
+    (0, {"OPT_DEFER_MARGIN_MILLI": -1000000000}),
+    (0, {"OPT_DEFER_MARGIN_MILLI": -4000}),
+    (0, {"OPT_DEFER_MARGIN_MILLI": 0, "OPT_PAIR_MIN_STARTS": 0}),
+    (0, {"OPT_DEFER_MARGIN_MILLI": 3000, "OPT_GATE_SPEED_MILLI": 700}),
+]
+
+
+@pytest.mark.parametrize("one_launch,options", SCHEDULES, ids=[f"{a}-{'-'.join(f'{k[4:]}={v}' for k, v in o.items()) or 'defaults'}"
+                                                           for a, o in SCHEDULES])
+def test_result_does_not_depend_on_the_schedule(P, golden24, one_launch, options):
+    """The STRIP kernel's schedule - a solve as one launch (ring policies, fill marks, gate per round, window,
+    how often the dead-edge cells are relaxed) or as a launch pair per pass, and the deferral of the
+    bits for units behind the front (off, eager, far too eager: the late relaxations then improve cells and
+    the solve goes on) - never changes a bit of the converged boxes: 818-FS, interior, corner and dead-edge
+    starts in one batch, against the reference's boxes."""
+    fs = P.inputs.make_fs(golden24.star("818"))
+    keys = ["818_mid", "818_corner", "818_deadin", "818_deadout"]
+    starts = np.array([golden24.z[f"start_{k}"] for k in keys], dtype=np.int32)
+    tts = []
+    for st in starts:
+        tt = np.full(golden24.v.shape, np.inf, dtype=np.float32)
+        tt[tuple(st)] = 0
+        tts.append(tt)
+    with P.TravelTimeSolver(golden24.v.shape, fs) as sol:
+        sol.set_option(P.OPT_ASYNC, one_launch)
+        for key, value in options.items():
+            sol.set_option(getattr(P, key), value)
+        sol.set_velocity(golden24.v)
+        assert sol.solve(starts, tts) == 1
+        st = sol.stats()
+        assert st["kernel_variant"] == 2 and (st["launches"] == 1) == bool(one_launch)
+        # ... and the converged boxes are recognised as such by the same schedule
+        again = [t.copy() for t in tts]
+    for k, tt in zip(keys, tts):
+        assert_bit_equal(tt, golden24.z[f"tt_{k}"], f"{k} {one_launch} {options}")
+    with P.TravelTimeSolver(golden24.v.shape, fs) as sol:
+        sol.set_option(P.OPT_ASYNC, one_launch)
+        for key, value in options.items():
+            sol.set_option(getattr(P, key), value)
+        sol.set_velocity(golden24.v)
+        assert sol.solve(starts, again) == 0        # (a fresh context: nothing is answered from digests)
+    for a, b in zip(again, tts):
+        assert_bit_equal(a, b, "idempotent")
 
 
 def test_converged_box_with_one_finite_unit_reports_no_change(P, oracle):
