@@ -265,8 +265,7 @@ int ttsweep_set_option(ttsweep_ctx *ctx, int key, long long value)
         (key == TTSWEEP_OPT_ASYNC_LOW ? ctx->async_low : ctx->async_high) = (int)value;
         return 0;
     case TTSWEEP_OPT_DEFER_MARGIN_MILLI:
-        (ctx->kernel == TTSWEEP_KERNEL_TILE ? ctx->tile_defer_margin : ctx->defer_margin) =
-            value <= -1000000000ll ? -3.0e38f : (float)((double)value / 1000.0);
+        ctx->defer_margin = value <= -1000000000ll ? -3.0e38f : (float)((double)value / 1000.0);
         return 0;
     case TTSWEEP_OPT_ASYNC_POLICY:
         if (value < 0 || value > 2) return set_error("ring policy must be 0, 1 or 2");

@@ -98,8 +98,6 @@ struct ttsweep_ctx {
     // STRIP: bits for units nearer to the start than the improved cells by more than this many cells are
     // deferred until the start is otherwise at rest (push_improved); < -1e30: off
     float defer_margin = 1.f;
-    float tile_defer_margin = 4.f;          // the same for the TILE kernel's stamps (tile centres; TTSWEEP_OPT_DEFER_MARGIN_MILLI
-                                            // sets the one of the kernel in use)
     // STRIP, one launch per solve (AsyncSolve, ttsweep_dev.h)
     int async_mode = -1;                    // TTSWEEP_OPT_ASYNC
     int async_low = 0, async_high = 0;      // 0: defaults (solve_async_strip)

@@ -263,7 +263,6 @@ struct TileSweep {
     int *state0;            // activity words of start 0 (StartDesc::tile_flags); start s: + s * state_stride ints
     long long state_stride; //   (the planner computes a start's addresses instead of loading its descriptor)
     unsigned long long *work0;  // work counters of start 0; start s: + 3 s
-    float defer_margin;     // tile_stamp_neighbours: neighbours nearer to the start by more than this are told late
     int fz;                 // max |dc|: layers per z face
     const float *vface;     // velocity faces
     float *tface;           // travel-time faces of start 0; start s: + s * face_cells

@@ -79,7 +79,6 @@ static int prepare_tile_sweep(ttsweep_ctx *ctx)
     P.state_stride = (long long)flag_words(ctx->L, ctx->kernel);
     P.work0 = ctx->d_work;
     P.fz = ctx->tile_fz;
-    P.defer_margin = ctx->tile_defer_margin;
     P.vface = ctx->d_vface;
     P.tface = ctx->d_tface;
     P.face_cells = tile_face_cells(ctx->L, ctx->tile_fz);
@@ -482,21 +481,13 @@ int solve_device_body(ttsweep_ctx *ctx, int nstart, const ttsweep_start *starts,
 
         // STRIP: every start is at rest; the bits that were deferred (push_improved: units behind the
         // front) become due now, and the starts that had any go on
-        const bool strip_defers = ctx->kernel == TTSWEEP_KERNEL_STRIP && !async && ctx->defer_margin > -1.0e30f;
-        const bool tile_defers = ctx->kernel == TTSWEEP_KERNEL_TILE && ctx->tile_defer_margin > -1.0e30f;
-        if (!strip_defers && !tile_defers) break;
+        if (ctx->kernel != TTSWEEP_KERNEL_STRIP || async || ctx->defer_margin < -1.0e30f) break;
         for (int s = 0; s < nstart; s++) ctx->h_active[s] = s;
         int *const dfl = ctx->d_changed + (size_t)PASS_SLOTS * nstart, *const hfl = ctx->h_changed + (size_t)PASS_SLOTS * nstart;
         HIPCHK(hipMemcpyAsync(ctx->d_active, ctx->h_active, nstart * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
         HIPCHK(hipMemsetAsync(dfl, 0, nstart * sizeof(int), ctx->stream));
-        if (strip_defers) {
-            HIPCHK(launch_flush_deferred(L, ctx->np, ctx->d_tile_flags, (long long)flag_words(L, ctx->kernel), ctx->d_active,
-                                         nstart, dfl, ctx->stream));
-        } else {
-            HIPCHK(launch_tile_flush_deferred(L, ctx->d_tile_flags, (long long)flag_words(L, ctx->kernel), ctx->d_active,
-                                              nstart, ++ctx->tile_epoch, dfl, ctx->stream));
-            ctx->h_tile_dmin[0] = ctx->h_tile_dmin[1] = 0;      // (the next sweep starts at its first hyperplane)
-        }
+        HIPCHK(launch_flush_deferred(L, ctx->np, ctx->d_tile_flags, (long long)flag_words(L, ctx->kernel), ctx->d_active,
+                                     nstart, dfl, ctx->stream));
         HIPCHK(hipMemcpyAsync(hfl, dfl, nstart * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
         HIPCHK(hipStreamSynchronize(ctx->stream));
         nactive = 0;
@@ -504,8 +495,7 @@ int solve_device_body(ttsweep_ctx *ctx, int nstart, const ttsweep_start *starts,
             if (hfl[s]) { ctx->h_active[nactive++] = s; done[s] = 0; }
         if (nactive == 0) break;
         HIPCHK(hipMemcpyAsync(ctx->d_active, ctx->h_active, nactive * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
-        if (strip_defers && build_worklist(ctx, nactive)) return -1;
-        if (tile_defers) HIPCHK(hipStreamSynchronize(ctx->stream));
+        if (build_worklist(ctx, nactive)) return -1;
     }
 
     for (int s = 0; s < nstart; s++)

@@ -101,10 +101,6 @@ hipError_t launch_tile_reduce_work(unsigned long long *wgwork, int nblocks, int 
 // from_box = false: only the start's tile counts as changed; true: every tile does.
 hipError_t launch_init_tile_state(const DevLayout &L, const StartDesc &sd, bool from_box, hipStream_t st);
 
-// the deferred marks (tile_stamp_neighbours) of the listed starts become due stamps of `epoch`; changed[s] |= 2
-hipError_t launch_tile_flush_deferred(const DevLayout &L, int *state0, long long state_stride, const int *active,
-                                      int nactive, int epoch, int *changed, hipStream_t st);
-
 #ifdef TTSWEEP_TILE_PROFILE
 void tile_prof_dump();   // prints and clears the phase counters of tile_sweep_kernel
 #endif

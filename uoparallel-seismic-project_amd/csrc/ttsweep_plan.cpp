@@ -372,7 +372,7 @@ size_t flag_words(const DevLayout &L, int kernel)
 {
     const size_t strip = kernel == TTSWEEP_KERNEL_STRIP
         ? 3 * (size_t)std::max(strip_units(L, 1), 1) + 4 : 0;      // (one-plane units: the larger grid)
-    const size_t tile = 3 * (size_t)tile_count(L.n[0], TILE_X) * tile_count(L.n[1], TILE_Y) * tile_count(L.n[2], TILE_Z);
+    const size_t tile = 2 * (size_t)tile_count(L.n[0], TILE_X) * tile_count(L.n[1], TILE_Y) * tile_count(L.n[2], TILE_Z);
     return (std::max(strip, tile) + 31) & ~(size_t)31;     // (even: the TILE kernel views them as int2; whole lines)
 }
 

@@ -63,7 +63,6 @@ init_tile_state_kernel(int2 *__restrict__ state, int NJ, int NK, int ntiles, int
     // (si < 0: a box that arrives with values in it - every tile is due)
     const bool near_start = si < 0 || (abs(I - si) <= 1 && abs(J - sj) <= 1 && abs(K - sk) <= 1);
     state[t] = make_int2(1, near_start ? 1 : 0);
-    reinterpret_cast<int *>(state + ntiles)[t] = 0;        // nothing deferred (tile_stamp_neighbours)
 }
 
 // First hyperplane of the NEXT ordering sweep that can hold a due tile: a workgroup keeps the
@@ -77,59 +76,15 @@ __device__ __forceinline__ int tile_next_plane(const TileSweep &P, int I, int J,
     return max(In + Jn + Kn - 3, 0);
 }
 
-// A tile of start-state `state` improved in this launch: its 27 neighbours have to look again -
-// at once those that are not nearer to the start (sa, sb, sc) than this tile by more than
-// P.defer_margin cells (centre to centre); the tiles BEHIND the front get a mark in their
-// deferred word instead (the third word of a tile, behind the int2 pairs), which counts only
-// when the start is otherwise at rest (tile_flush_deferred_kernel): they are then relaxed once,
-// against final values, instead of in every sweep in which a tile in front of them improved.
-// Every mark is honoured before a solve ends, so the fixed point is the same.
+// A tile of start-state `state` improved in this launch: its 27 neighbours have to look again.
 __device__ __forceinline__ void tile_stamp_neighbours(const TileSweep &P, int2 *__restrict__ state, int I, int J, int K,
-                                                      int lane, int sa, int sb, int sc)
+                                                      int lane)
 {
     if (lane < 27) {
         const int ni = I + lane / 9 - 1, nj = J + (lane / 3) % 3 - 1, nk = K + lane % 3 - 1;
-        if ((unsigned)ni < (unsigned)P.NI && (unsigned)nj < (unsigned)P.NJ && (unsigned)nk < (unsigned)P.NK) {
-            const float da = (float)(I * TILE_X + TILE_X / 2 - sa), db = (float)(J * TILE_Y + TILE_Y / 2 - sb),
-                        dc = (float)(K * TILE_Z + TILE_Z / 2 - sc);
-            const float lim = sqrtf(da * da + db * db + dc * dc) - P.defer_margin;
-            const float ta = (float)(ni * TILE_X + TILE_X / 2 - sa), tb = (float)(nj * TILE_Y + TILE_Y / 2 - sb),
-                        tc = (float)(nk * TILE_Z + TILE_Z / 2 - sc);
-            const int n = (ni * P.NJ + nj) * P.NK + nk;
-            if (P.defer_margin > -1.0e30f && lim > 0.f && ta * ta + tb * tb + tc * tc < lim * lim)
-                reinterpret_cast<int *>(state + (long long)P.NI * P.NJ * P.NK)[n] = 1;
-            else
-                state[n].y = P.epoch;
-        }
+        if ((unsigned)ni < (unsigned)P.NI && (unsigned)nj < (unsigned)P.NJ && (unsigned)nk < (unsigned)P.NK)
+            state[(ni * P.NJ + nj) * P.NK + nk].y = P.epoch;
     }
-}
-
-// The deferred marks of the listed starts become "look again" stamps of epoch `epoch`;
-// changed[s] |= 2 where there was one.
-__global__ void __launch_bounds__(256)
-tile_flush_deferred_kernel(int *__restrict__ state0, long long state_stride, int ntiles, const int *__restrict__ active,
-                           int epoch, int *__restrict__ changed)
-{
-    const int t = blockIdx.x * 256 + threadIdx.x;
-    if (t >= ntiles) return;
-    const int s = active[blockIdx.y];
-    int2 *const state = reinterpret_cast<int2 *>(state0 + (long long)s * state_stride);
-    int *const defer = reinterpret_cast<int *>(state + ntiles);
-    if (defer[t]) {
-        defer[t] = 0;
-        state[t].y = epoch;
-        atomicOr(&changed[s], 2);
-    }
-}
-
-hipError_t launch_tile_flush_deferred(const DevLayout &L, int *state0, long long state_stride, const int *active,
-                                      int nactive, int epoch, int *changed, hipStream_t st)
-{
-    if (nactive <= 0) return hipSuccess;
-    const int ntiles = tile_count(L.n[0], TILE_X) * tile_count(L.n[1], TILE_Y) * tile_count(L.n[2], TILE_Z);
-    hipLaunchKernelGGL(tile_flush_deferred_kernel, dim3((ntiles + 255) / 256, nactive), dim3(256), 0, st,
-                       state0, state_stride, ntiles, active, epoch, changed);
-    return hipGetLastError();
 }
 
 hipError_t launch_init_tile_state(const DevLayout &L, const StartDesc &sd, bool from_box, hipStream_t st)
@@ -585,7 +540,7 @@ tile_sweep_kernel(TileSweep P)
                     tf[tile_face_index(L, FZ, K + 1, 0, l, pa, pb)] = timg[row0 + TILE_Z - FZ + l];
                 }
             }
-            tile_stamp_neighbours(P, state, I, J, K, lane, sa, sb, sc);
+            tile_stamp_neighbours(P, state, I, J, K, lane);
             tile_work_improved(work, act, lane);
             first_next = min(first_next, tile_next_plane(P, I, J, K));
         }
@@ -761,9 +716,6 @@ tile_six_kernel(TileSweep P)
         // (the start's volume and activity words from the launch arguments: no descriptor load)
         float *const T = uni_ptr(P.T0 + (long long)s * L.cells);
         int2 *const state = uni_ptr(reinterpret_cast<int2 *>(P.state0 + (long long)s * P.state_stride));
-        // (the start's coordinates, for the stamps at the tile's end: scalar loads that travel meanwhile)
-        const const_start_ptr sdp = (const_start_ptr)(P.starts + s);
-        const int sa = sdp->sa, sb = sdp->sb, sc = sdp->sc;
         PROF_STAMP(t_top);
         const int K = tile % P.NK, J = (tile / P.NK) % P.NJ, I = tile / (P.NK * P.NJ);
 
@@ -832,7 +784,7 @@ tile_six_kernel(TileSweep P)
             const int pa = I * TILE_X + 1 + ci, pb = J * TILE_Y + 1 + cj;
             tface[tile_face_index(L, 1, K, 1, 0, pa, pb)] = img[SIXC_T + row * TILE_Z];
             tface[tile_face_index(L, 1, K + 1, 0, 0, pa, pb)] = img[SIXC_T + row * TILE_Z + TILE_Z - 1];
-            tile_stamp_neighbours(P, state, I, J, K, lane, sa, sb, sc);
+            tile_stamp_neighbours(P, state, I, J, K, lane);
             tile_work_improved(work, act, lane);
             first_next = min(first_next, tile_next_plane(P, I, J, K));
         }
