@@ -123,6 +123,10 @@ typedef struct ttsweep_ctx ttsweep_ctx;
 #define TTSWEEP_OPT_ASYNC_GATE_MILLI 16 /* schedule only: ring policy 1 - cells (x 1/1000) by which the distance gate
                                          opens per round of a one-launch solve (default 750; 0 = no gate;
                                          TTSWEEP_OPT_GATE_SPEED_MILLI = 0 switches this gate off as well) */
+#define TTSWEEP_OPT_ASYNC_GATE_FAST_MILLI 17 /* schedule only: ring policy 1 - cells (x 1/1000) by which the gate opens
+                                         in a round that begins with an empty ring (the workers are running dry);
+                                         never less than TTSWEEP_OPT_ASYNC_GATE_MILLI */
+
 #define TTSWEEP_KERNEL_AUTO       0
 #define TTSWEEP_KERNEL_CELL       1   /* one thread per cell, star from global memory */
 #define TTSWEEP_KERNEL_STRIP      2   /* LDS-staged plane slabs, register strips */

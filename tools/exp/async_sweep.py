@@ -1,5 +1,5 @@
 """Knob sweep of the one-launch STRIP solve on the headline grid.
-usage: async_sweep.py nstarts cfg [cfg ...]   cfg = async:pair:low:high:special:policy:gate_milli:margin_milli  (pair -1 = default rule, gate -1 = default, margin -1000000000 = off)"""
+usage: async_sweep.py nstarts cfg [cfg ...]   cfg = async:pair:low:high:special:policy:gate_milli:margin_milli[:fast_gate_milli]  (pair -1 = default rule, gate -1 = default, margin -1000000000 = off)"""
 import os, sys, json, hashlib, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch, ttsweep_pkg
@@ -18,7 +18,9 @@ starts = np.asarray(P.inputs.read_triples(P.inputs.starts_path("24")), dtype=np.
 dev = torch.device("cuda:0")
 tt = torch.empty((len(starts),) + v.shape, dtype=torch.float32, device=dev)
 for cfg in sys.argv[2:]:
-    mode, pair, low, high, special, policy, gate, margin = (int(x) for x in cfg.split(":"))
+    f = [int(x) for x in cfg.split(":")]
+    mode, pair, low, high, special, policy, gate, margin = f[:8]
+    fast = f[8] if len(f) > 8 else -1
     # (policy 2: `gate` is the window in milli-cells)
     with P.TravelTimeSolver(v.shape, fs) as sol:
         sol.set_option(P.OPT_TIMING, 1)
@@ -31,6 +33,7 @@ for cfg in sys.argv[2:]:
         sol.set_option(P.OPT_ASYNC_POLICY, policy)
         if gate >= 0: sol.set_option(P.OPT_ASYNC_WINDOW_MILLI if policy == 2 else (P.OPT_ASYNC_GATE_MILLI if mode == 1 else P.OPT_GATE_SPEED_MILLI), gate)
         sol.set_option(P.OPT_DEFER_MARGIN_MILLI, margin)
+        if fast >= 0: sol.set_option(P.OPT_ASYNC_GATE_FAST_MILLI, fast)
         best = None
         for rep in range(3):
             rc = sol.solve_device(starts, tt, init=True)

@@ -35,6 +35,9 @@ bash tools/exp/pmc.sh r3sq2 "--steps 2 --warmup 1 --no-hbm-regime" sweep_units S
 bash tools/exp/pmc.sh r3sq3 "--steps 2 --warmup 1 --no-hbm-regime --star six --grid 1024,1024,512 --starts 111 --nstarts 14" tile_six SQ_LDS_IDX_ACTIVE SQ_WAVE_CYCLES SQ_BUSY_CU_CYCLES SQ_WAIT_ANY SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT > $O/pmc_sq3.txt 2>&1
 for f in 1 2 3; do tail -n 1 $O/pmc_sq$f.txt; done
 rm -rf gpurun_out/pmc_r3sq1 gpurun_out/pmc_r3sq2 gpurun_out/pmc_r3sq3
+echo "== summary"
+for f in $O/*line.json; do
+python3 - "$f" <<'PY'
 import json,sys,os
 f=sys.argv[1]
 try:

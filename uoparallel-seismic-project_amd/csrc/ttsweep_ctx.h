@@ -104,6 +104,7 @@ struct ttsweep_ctx {
     int async_special_every = 128;
     int async_policy = 1;                   // TTSWEEP_OPT_ASYNC_POLICY
     float async_gate_speed = 0.75f;         // cells per round (policy 1; TTSWEEP_OPT_ASYNC_GATE_MILLI)
+    float async_gate_fast = 2.0f;           // ... while the workers are running dry (TTSWEEP_OPT_ASYNC_GATE_FAST_MILLI)
     float async_window = 16.f;              // TTSWEEP_OPT_ASYNC_WINDOW_MILLI
     int4 *d_async_list = nullptr;           // the rings' unit lists
     size_t async_list_cap = 0;

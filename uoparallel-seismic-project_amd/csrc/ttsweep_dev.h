@@ -183,6 +183,7 @@ struct AsyncSolve {
                                     // 2: as 1, but the gate of a start lies `window` cells beyond the nearest of its
                                     //    units that the previous round found with anything to do
     float gate_r0, gate_speed;      // policy 1; speed <= 0: no gate
+    float gate_fast;                // policy 1: cells per round while the ring is empty at the beginning of a round
     float window;                   // policy 2; <= 0: no gate
     int scan_slack;                 // list entries in front of the first unit with anything to do that a round still scans
     int ring_off[ASYNC_MAX_RINGS], ring_len[ASYNC_MAX_RINGS];

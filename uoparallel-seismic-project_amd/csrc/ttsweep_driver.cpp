@@ -193,7 +193,7 @@ static bool use_async(const ttsweep_ctx *ctx, int nstart)
 // first, the starts interleaved rank by rank), the ring memory, the launch, its verdict.
 // sweeps[s]: whole-grid equivalents of units relaxed for start s (what a pass count is for the
 // pass driver).  Returns 1 / 0 (something improved / nothing did) or < 0.
-static int solve_async_strip(ttsweep_ctx *ctx, int nstart, bool single_source, std::vector<int> &sweeps)
+static int solve_async_strip(ttsweep_ctx *ctx, int nstart, std::vector<int> &sweeps)
 {
     const StripPlan &plan = ctx->plans[ctx->np - 1];
     const int nunits = strip_units(ctx->L, ctx->np);
@@ -210,8 +210,9 @@ static int solve_async_strip(ttsweep_ctx *ctx, int nstart, bool single_source, s
     // lists
     as.policy = ctx->async_policy;
     as.gate_r0 = (float)ctx->gate_r0;
-    as.gate_speed = single_source && ctx->gate_speed > 0 ? ctx->async_gate_speed : 0.f;      // (the gate is for solves that grow from one unit)
-    as.window = single_source ? ctx->async_window : 0.f;
+    as.gate_speed = ctx->gate_speed > 0 ? ctx->async_gate_speed : 0.f;     // (per start: only for boxes that grow from one unit)
+    as.gate_fast = std::max(ctx->async_gate_fast, as.gate_speed);
+    as.window = ctx->async_window;
     const int btiles = strip_btiles(ctx->L), cstrips = strip_cstrips(ctx->L);
     auto gate_d2 = [&](int s, int unit) {       // squared distance from the start to the unit's cells (plan_pass_kernel)
         const StartDesc &sd = ctx->h_starts[s];
@@ -399,7 +400,7 @@ int solve_device_body(ttsweep_ctx *ctx, int nstart, const ttsweep_start *starts,
     bool anychange_ever = false;
     auto t_pass = std::chrono::steady_clock::now();
     if (async) {
-        const int rc = solve_async_strip(ctx, nstart, init != 0, sweeps);
+        const int rc = solve_async_strip(ctx, nstart, sweeps);
         if (rc < 0) return rc;
         anychange_ever = rc > 0;
         nactive = 0;

@@ -1095,7 +1095,7 @@ __device__ __forceinline__ void async_fail(const AsyncSolve &as, unsigned code)
 
 // Planner of ring r: all 256 threads of one workgroup.  `lds`: scratch words of its own.
 template <int NP>
-__device__ __noinline__ void async_planner(const DevLayout &L, const StartDesc *__restrict__ starts, const AsyncSolve &as,
+__device__ __forceinline__ void async_planner(const DevLayout &L, const StartDesc *__restrict__ starts, const AsyncSolve &as,
                                            const int r, const int btiles, const int cstrips, const int ra,
                                            const PlaneCounts &pc, int *__restrict__ flags0, const long long flags_stride,
                                            int *lds)
@@ -1116,7 +1116,11 @@ __device__ __noinline__ void async_planner(const DevLayout &L, const StartDesc *
     int *dirty = lds + 8 + KSCAN * STRIP_NS;    // [ASYNC_RING_STARTS] units published since the start's last special
     int *minact = dirty + ASYNC_RING_STARTS;    // [ASYNC_RING_STARTS] smallest squared distance (float bits) met with work, this round
     float *gate2 = reinterpret_cast<float *>(minact + ASYNC_RING_STARTS);      // [ASYNC_RING_STARTS] squared gate radius per start
+    // (the gate is for boxes that grow from ONE source patch - what the initialisation counted -: a box
+    // that arrives with values all over it, e.g. a converged one, is relaxed ungated)
+    int *gated = reinterpret_cast<int *>(gate2 + ASYNC_RING_STARTS);
     if (tid < ASYNC_RING_STARTS) {
+        gated[tid] = tid < ns ? flags0[(long long)rstarts[tid] * flags_stride + 3 * nflag] == 1 : 0;
         dirty[tid] = tid < ns ? 1 : 0;          // (the first thing a ring does: its starts' dead-edge cells)
         minact[tid] = 0;                        // (the first round: the window around the start itself)
         if (tid == 0) sh[4] = 0x7fffffff;
@@ -1129,7 +1133,7 @@ __device__ __noinline__ void async_planner(const DevLayout &L, const StartDesc *
     // whether the ring was at rest when it began, whether it met a word that was not zero
     int base = n, round = -1, activity = 0;
     bool quiet = false, from_zero = true;
-    float gate_r2 = 3.0e38f;
+    float gate_r2 = 3.0e38f, gate_r = as.gate_r0;
 
     // publishes the dead-edge entries of the ring's starts whose counter has reached `threshold`
     auto publish_specials = [&](int threshold) -> int {
@@ -1196,8 +1200,11 @@ __device__ __noinline__ void async_planner(const DevLayout &L, const StartDesc *
             from_zero = base == 0;
             quiet = c == t;                     // nothing queued, nothing running: the scan sees a still picture
             activity = 0;
-            const float gr = as.gate_r0 + as.gate_speed * (float)round;
-            gate_r2 = as.policy == 1 && as.gate_speed > 0.f ? gr * gr : 3.0e38f;
+            // the gate opens by gate_speed cells per round while the workers have enough to do, by
+            // gate_fast when they are running dry (everything published has been claimed): few starts
+            // cannot fill the machine from behind a slow gate, many starts waste work behind a fast one
+            if (round > 0) gate_r += (int)(t - h) <= 0 ? as.gate_fast : as.gate_speed;
+            gate_r2 = as.policy == 1 && as.gate_speed > 0.f ? gate_r * gate_r : 3.0e38f;
             if (as.policy == 2) {
                 // window: a start's units are handed out up to `window` cells beyond the nearest unit
                 // the previous round met with anything to do (everything, if it met none)
@@ -1222,7 +1229,7 @@ __device__ __noinline__ void async_planner(const DevLayout &L, const StartDesc *
                 const int idx = base + k * 256 + tid;
                 int4 it = make_int4(0, -1, 0, 0);
                 if (idx < n) it = list[idx];
-                if (__int_as_float(it.z) > (as.policy == 2 ? gate2[it.x >> 16] : gate_r2)) {   // behind the gate: not even looked at (the round ends
+                if (gated[it.x >> 16] && __int_as_float(it.z) > (as.policy == 2 ? gate2[it.x >> 16] : gate_r2)) {   // behind the gate: not even looked at (the round ends
                     if (it.y >= 0) activity = 1;        // where a whole step lies behind it); may hold bits
                     it.y = -1;
                 } else if (it.y >= 0) {
@@ -1343,7 +1350,7 @@ __device__ __noinline__ void async_planner(const DevLayout &L, const StartDesc *
 
 // Worker, thread 0: the next ring entry (own ring first), or ASYNC_EXIT when every ring is done
 // or the solve has failed.  *ring: the ring the entry came from.
-__device__ __noinline__ unsigned long long async_claim(const AsyncSolve &as, const int home, int *ring, const long long clock0)
+__device__ __forceinline__ unsigned long long async_claim(const AsyncSolve &as, const int home, int *ring, const long long clock0)
 {
     for (unsigned spin = 0;; spin++) {
         int ndone = 0;
