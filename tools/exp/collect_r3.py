@@ -50,7 +50,7 @@ u = dict(c1, **c2)
 out = {
     "command": "rocprofv3 --pmc <8 SQ counters per run> --kernel-trace --output-format csv -- python3 bench.py --steps 2 --warmup 1 "
                "--no-cpu --no-traffic --no-host --no-hbm-regime (tools/exp/pmc.sh, called by tools/exp/r3final.sh)",
-    "kernel": f"sweep_units_kernel<16, 2>, sums over all launches of the run ({n1} launches)",
+    "kernel": f"sweep_units_kernel<16, 2, true> (one launch per solve), sums over all launches of the run ({n1} launches)",
     "counters": u,
     "derived": {
         "wave time waiting (SQ_WAIT_ANY / SQ_WAVE_CYCLES)": round(u["SQ_WAIT_ANY"] / u["SQ_WAVE_CYCLES"], 3),
