@@ -315,7 +315,10 @@ int solve_device_body(ttsweep_ctx *ctx, int nstart, const ttsweep_start *starts,
     // units of two planes when there are starts enough to fill the machine with them
     const bool pairs = ctx->pair_min_starts >= 0
         ? nstart >= ctx->pair_min_starts
-        : (long long)nstart * strip_units(L, 1) >= ctx->pair_min_units;
+        : (long long)nstart * strip_units(L, 1) >= (ctx->async_mode != 0 ? ctx->pair_min_units / 2 : ctx->pair_min_units);
+        // (measured crossovers on 241x241x51: the pass driver from 21 starts on, the one-launch driver - whose
+        // shorter units pay the same claim and completion - from about 10: 8 starts 14.7 (one plane) / 15.7 ms (two),
+        // 12 starts 24.1 / 22.8, 16 starts 28.5 / 26.3, 24 starts 42.1 / 36.9)
     const int np = pairs ? STRIP_PLANES : 1;
     if (np != ctx->np) ctx->unit_order_key.assign(ctx->unit_order_key.size(), -1);     // orders belong to the other unit grid
     ctx->np = np;
