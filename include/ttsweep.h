@@ -126,6 +126,10 @@ typedef struct ttsweep_ctx ttsweep_ctx;
 #define TTSWEEP_OPT_ASYNC_GATE_FAST_MILLI 17 /* schedule only: ring policy 1 - cells (x 1/1000) by which the gate opens
                                          in a round that begins with an empty ring (the workers are running dry);
                                          never less than TTSWEEP_OPT_ASYNC_GATE_MILLI */
+#define TTSWEEP_OPT_ASYNC_TIMEOUT_MILLI 18 /* wall-clock limit (ms) of every wait inside a one-launch solve; when one
+                                         runs into it the launch drains and the pass driver finishes the solve from
+                                         the boxes as they stand (same result).  0 (default): ten seconds plus
+                                         twenty times the solve's expected duration */
 
 #define TTSWEEP_KERNEL_AUTO       0
 #define TTSWEEP_KERNEL_CELL       1   /* one thread per cell, star from global memory */

@@ -705,6 +705,34 @@ def test_result_does_not_depend_on_the_schedule(P, golden24, one_launch, options
         assert_bit_equal(a, b, "idempotent")
 
 
+def test_one_launch_solve_that_gives_up_is_finished_by_the_pass_driver(P, full):
+    """Every wait inside the one-launch solve has a wall-clock limit, so that a protocol error could not
+    hang the device.  Here the limit is set absurdly low (1 ms; the 4-start full-size solve takes ~10): the
+    launch drains with the boxes somewhere on their way, the pass driver takes over from them, and the
+    converged boxes are the reference's, bit for bit (SHA-256 of the reference's own runs)."""
+    digests = json.load(open(os.path.join(GOLDEN, "big_digests.json")))
+    cases = []
+    for key, want in digests.items():
+        _, sname, i, j, k = key.split("_")
+        if sname == "818" and len(cases) < 4:
+            cases.append(((int(i), int(j), int(k)), want["sha256"]))
+    fs = P.inputs.make_fs(P.inputs.read_triples(P.inputs.star_path("818")))
+    starts = np.array([c[0] for c in cases], dtype=np.int32)
+    tts = []
+    for st in starts:
+        tt = np.full(full.shape, np.inf, dtype=np.float32)
+        tt[tuple(st)] = 0
+        tts.append(tt)
+    with P.TravelTimeSolver(full.shape, fs) as sol:
+        sol.set_option(P.OPT_ASYNC, 1)
+        sol.set_option(P.OPT_ASYNC_TIMEOUT_MILLI, 1)
+        sol.set_velocity(full)
+        assert sol.solve(starts, tts) == 1
+        assert sol.stats()["launches"] > 2          # (the one launch, then passes)
+    for tt, (start, want) in zip(tts, cases):
+        assert hashlib.sha256(tt.tobytes()).hexdigest() == want, start
+
+
 def test_converged_box_with_one_finite_unit_reports_no_change(P, oracle):
     """A star that only moves along z reaches one z-column: every finite cell sits in ONE
     activity unit, which is exactly the case the distance gate treats as "grown from one

@@ -279,6 +279,10 @@ int ttsweep_set_option(ttsweep_ctx *ctx, int key, long long value)
         if (value < 0) return set_error("gate speed must be >= 0");
         ctx->async_gate_fast = (float)((double)value / 1000.0);
         return 0;
+    case TTSWEEP_OPT_ASYNC_TIMEOUT_MILLI:
+        if (value < 0 || value > 3600000) return set_error("time limit must lie in [0, 3600000] ms");
+        ctx->async_timeout_ms = (int)value;
+        return 0;
     case TTSWEEP_OPT_ASYNC_WINDOW_MILLI:
         if (value < 0) return set_error("window must be >= 0");
         ctx->async_window = (float)((double)value / 1000.0);

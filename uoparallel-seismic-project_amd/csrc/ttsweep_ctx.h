@@ -102,6 +102,7 @@ struct ttsweep_ctx {
     int async_mode = -1;                    // TTSWEEP_OPT_ASYNC
     int async_low = 0, async_high = 0;      // 0: defaults (solve_async_strip)
     int async_special_every = 128;
+    int async_timeout_ms = 0;               // TTSWEEP_OPT_ASYNC_TIMEOUT_MILLI (0: from the size of the solve)
     int async_policy = 1;                   // TTSWEEP_OPT_ASYNC_POLICY
     float async_gate_speed = 0.75f;         // cells per round (policy 1; TTSWEEP_OPT_ASYNC_GATE_MILLI)
     float async_gate_fast = 2.0f;           // ... while the workers are running dry (TTSWEEP_OPT_ASYNC_GATE_FAST_MILLI)

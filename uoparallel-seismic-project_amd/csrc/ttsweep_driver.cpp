@@ -269,7 +269,12 @@ static int solve_async_strip(ttsweep_ctx *ctx, int nstart, std::vector<int> &swe
     as.entries = ctx->d_async_entries;
     as.ctl = ctx->d_async_ctl;
     as.status = ctx->d_async_status;
-    as.timeout_ticks = 10ll * 100000000ll;          // ten seconds of wall clock (100 MHz): far beyond any solve this mode is chosen for
+    // every wait inside the launch gives up after this much wall clock (100 MHz ticks): ten seconds plus
+    // twenty times what the solve should take at a tenth of the machine's rate (1024x1024x512 x 14 with
+    // the 818-offset star: 5.6 s measured, limit about 130 s) - a protocol error must not hang the device
+    const double expect_s = (double)ctx->relax_per_sweep * (double)nstart * 8.0 / 1.0e12;
+    as.timeout_ticks = (long long)((10.0 + 20.0 * expect_s) * 1.0e8);
+    if (ctx->async_timeout_ms > 0) as.timeout_ticks = (long long)ctx->async_timeout_ms * 100000ll;
     long long longest = 0;
     for (int r = 0; r < as.nrings; r++) longest = std::max<long long>(longest, as.ring_len[r]);
     as.max_entries = (long long)std::min<double>((double)ctx->max_sweeps * (double)longest, 2.0e9);
@@ -297,8 +302,10 @@ static int solve_async_strip(ttsweep_ctx *ctx, int nstart, std::vector<int> &swe
 #endif
     if (ctx->h_async_status[0] == ASYNC_ERR_CAP)
         return set_error("a start did not converge in %lld sweeps", ctx->max_sweeps);
-    if (ctx->h_async_status[0] != ASYNC_OK)
-        return set_error("the one-launch solve gave up (code %u)", ctx->h_async_status[0]);
+    if (ctx->h_async_status[0] != ASYNC_OK) {
+        set_error("the one-launch solve gave up (code %u)", ctx->h_async_status[0]);
+        return -2;      // (the boxes hold valid upper bounds: the caller goes on with the pass driver)
+    }
     bool any = false;
     for (int s = 0; s < nstart; s++) {
         any |= (ctx->h_changed[s] & CHANGED_IMPROVED) != 0;
@@ -374,7 +381,7 @@ int solve_device_body(ttsweep_ctx *ctx, int nstart, const ttsweep_start *starts,
     ctx->pass_index = 0;
     ctx->tile_epoch = 1;
     if (ctx->kernel == TTSWEEP_KERNEL_TILE && prepare_tile_sweep(ctx)) return -1;
-    const bool async = use_async(ctx, nstart);
+    bool async = use_async(ctx, nstart);
     if (ctx->kernel == TTSWEEP_KERNEL_STRIP && !async) {
         if (build_worklist(ctx, nstart)) return -1;
         // the passes keep these cleared themselves from here on
@@ -404,9 +411,23 @@ int solve_device_body(ttsweep_ctx *ctx, int nstart, const ttsweep_start *starts,
     auto t_pass = std::chrono::steady_clock::now();
     if (async) {
         const int rc = solve_async_strip(ctx, nstart, sweeps);
-        if (rc < 0) return rc;
-        anychange_ever = rc > 0;
-        nactive = 0;
+        if (rc == -2) {
+            // A wait inside the launch ran into its wall-clock limit.  Every travel time in the boxes is
+            // the length of a real path, so the pass driver takes over from there: activity words as for
+            // boxes that arrive with values in them, then passes until nothing changes.
+            for (int s = 0; s < nstart; s++)
+                HIPCHK(launch_init_tile_flags(L, ctx->h_starts[s], /*from_box=*/true, ctx->plans[np - 1].ra, np, ctx->stream));
+            if (build_worklist(ctx, nstart)) return -1;
+            HIPCHK(hipMemsetAsync(ctx->d_changed, 0, (size_t)PASS_SLOTS * nstart * sizeof(int), ctx->stream));
+            HIPCHK(hipMemsetAsync(ctx->d_unitq_ctrl, 0, (UNITQ_CTRL_WORDS + 1) * sizeof(int), ctx->stream));
+            for (int s = 0; s < nstart; s++) sweeps[s] = 0;
+            anychange_ever = true;
+            async = false;
+        } else {
+            if (rc < 0) return rc;
+            anychange_ever = rc > 0;
+            nactive = 0;
+        }
     }
     for (;;) {
     while (processed < launched || nactive > 0) {
