@@ -234,6 +234,7 @@ int ttsweep_set_option(ttsweep_ctx *ctx, int key, long long value)
         ctx->d_T = nullptr;
         ctx->capacity_starts = 0;
         ctx->unit_order_key.assign(ctx->unit_order_key.size(), -1);     // orders belong to the old layout
+        ctx->async_list_key.clear();
         HIPCHK(hipMalloc((void **)&ctx->d_v, (size_t)ctx->L.cells * sizeof(float)));
         if (upload_star(ctx)) return -1;
         if (k == TTSWEEP_KERNEL_STRIP && upload_strip_plan(ctx)) return -1;

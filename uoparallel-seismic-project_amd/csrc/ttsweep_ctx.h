@@ -109,6 +109,8 @@ struct ttsweep_ctx {
     float async_window = 16.f;              // TTSWEEP_OPT_ASYNC_WINDOW_MILLI
     int4 *d_async_list = nullptr;           // the rings' unit lists
     size_t async_list_cap = 0;
+    std::vector<long long> async_list_key;  // unit grid, rings and start cells the lists on the device were made for
+    ttsweep::AsyncSolve async_rings{};      // ... and their ring offsets
     int *d_async_ring_starts = nullptr;     // ASYNC_MAX_STARTS
     unsigned long long *d_async_entries = nullptr, *d_async_ctl = nullptr;
     unsigned *d_async_status = nullptr, *h_async_status = nullptr;     // (pinned)

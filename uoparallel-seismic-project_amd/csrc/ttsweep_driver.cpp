@@ -226,10 +226,21 @@ static int solve_async_strip(ttsweep_ctx *ctx, int nstart, std::vector<int> &swe
         memcpy(&bits, &d2, sizeof bits);
         return bits;
     };
+    // (the lists depend on the start cells and the unit grid only: a solve of the same starts keeps them)
+    std::vector<long long> key;
+    key.reserve(nstart + 2);
+    key.push_back(ctx->np);
+    key.push_back(as.nrings);
+    for (int s = 0; s < nstart; s++) key.push_back(ctx->h_starts[s].sidx);
+    const bool cached = key == ctx->async_list_key && ctx->d_async_list;
     std::vector<int4> flat;
-    flat.reserve((size_t)nstart * nunits);
+    if (!cached) flat.reserve((size_t)nstart * nunits);
     std::vector<int> ring_starts;
-    for (int r = 0; r < as.nrings; r++) {
+    if (cached) {
+        for (int r = 0; r < ASYNC_MAX_RINGS; r++) { as.ring_off[r] = ctx->async_rings.ring_off[r]; as.ring_len[r] = ctx->async_rings.ring_len[r]; }
+        for (int r = 0; r <= ASYNC_MAX_RINGS; r++) as.ring_start_off[r] = ctx->async_rings.ring_start_off[r];
+    }
+    for (int r = 0; r < as.nrings && !cached; r++) {
         as.ring_off[r] = (int)flat.size();
         as.ring_start_off[r] = (int)ring_starts.size();
         std::vector<int> mine;
@@ -242,9 +253,9 @@ static int solve_async_strip(ttsweep_ctx *ctx, int nstart, std::vector<int> &swe
                                          gate_d2(mine[i], ctx->unit_order[mine[i]][k]), 0));
         as.ring_len[r] = (int)flat.size() - as.ring_off[r];
     }
-    as.ring_start_off[as.nrings] = (int)ring_starts.size();
+    if (!cached) as.ring_start_off[as.nrings] = (int)ring_starts.size();
     as.scan_slack = 16384 * ((nstart + as.nrings - 1) / as.nrings);
-    if (flat.size() > ctx->async_list_cap) {
+    if (!cached && flat.size() > ctx->async_list_cap) {
         if (ctx->d_async_list) HIPCHK(hipFree(ctx->d_async_list));
         ctx->d_async_list = nullptr;
         ctx->async_list_cap = 0;
@@ -256,14 +267,21 @@ static int solve_async_strip(ttsweep_ctx *ctx, int nstart, std::vector<int> &swe
     if (!ctx->d_async_ctl) HIPCHK(hipMalloc((void **)&ctx->d_async_ctl, (size_t)ASYNC_MAX_RINGS * ASYNC_CTL_STRIDE * sizeof(unsigned long long)));
     if (!ctx->d_async_status) HIPCHK(hipMalloc((void **)&ctx->d_async_status, 8 * sizeof(unsigned)));
     if (!ctx->h_async_status) HIPCHK(hipHostMalloc((void **)&ctx->h_async_status, 8 * sizeof(unsigned)));
-    HIPCHK(hipMemcpyAsync(ctx->d_async_list, flat.data(), flat.size() * sizeof(int4), hipMemcpyHostToDevice, ctx->stream));
-    HIPCHK(hipMemcpyAsync(ctx->d_async_ring_starts, ring_starts.data(), ring_starts.size() * sizeof(int),
-                          hipMemcpyHostToDevice, ctx->stream));
+    if (!cached) {
+        ctx->async_list_key.clear();        // (until the upload below has completed)
+        HIPCHK(hipMemcpyAsync(ctx->d_async_list, flat.data(), flat.size() * sizeof(int4), hipMemcpyHostToDevice, ctx->stream));
+        HIPCHK(hipMemcpyAsync(ctx->d_async_ring_starts, ring_starts.data(), ring_starts.size() * sizeof(int),
+                              hipMemcpyHostToDevice, ctx->stream));
+    }
     HIPCHK(hipMemsetAsync(ctx->d_async_entries, 0xff, (size_t)ASYNC_MAX_RINGS * cap * sizeof(unsigned long long), ctx->stream));
     HIPCHK(hipMemsetAsync(ctx->d_async_ctl, 0, (size_t)ASYNC_MAX_RINGS * ASYNC_CTL_STRIDE * sizeof(unsigned long long), ctx->stream));
     HIPCHK(hipMemsetAsync(ctx->d_async_status, 0, 8 * sizeof(unsigned), ctx->stream));
     HIPCHK(hipMemsetAsync(ctx->d_changed, 0, (size_t)nstart * sizeof(int), ctx->stream));
-    HIPCHK(hipStreamSynchronize(ctx->stream));      // (`flat` is a stack-lifetime buffer)
+    if (!cached) {
+        HIPCHK(hipStreamSynchronize(ctx->stream));  // (`flat` is a stack-lifetime buffer)
+        ctx->async_list_key = key;
+        ctx->async_rings = as;
+    }
     as.list = ctx->d_async_list;
     as.ring_starts = ctx->d_async_ring_starts;
     as.entries = ctx->d_async_entries;
@@ -347,6 +365,9 @@ int solve_device_body(ttsweep_ctx *ctx, int nstart, const ttsweep_start *starts,
         }
         sd.tile_flags = ctx->d_tile_flags + (size_t)s * flag_words(L, ctx->kernel);
         sd.work = ctx->d_work + 3 * s;
+        // (STRIP, fresh boxes: one launch for all starts further down)
+        const bool batched = init && ctx->kernel == TTSWEEP_KERNEL_STRIP && L.cells % 4 == 0 && nstart <= 65535;
+        if (batched) { ctx->h_active[s] = s; continue; }
         if (init) HIPCHK(launch_init_tt(L, sd.T, sd.sidx, ctx->stream));
         else HIPCHK(launch_pack(L, tt_dev[s], sd.T, INFINITY, ctx->stream));
         if (ctx->kernel == TTSWEEP_KERNEL_STRIP)
@@ -375,6 +396,11 @@ int solve_device_body(ttsweep_ctx *ctx, int nstart, const ttsweep_start *starts,
     }
     HIPCHK(hipMemcpyAsync(ctx->d_starts, ctx->h_starts, nstart * sizeof(StartDesc),
                           hipMemcpyHostToDevice, ctx->stream));
+    if (init && ctx->kernel == TTSWEEP_KERNEL_STRIP && L.cells % 4 == 0 && nstart <= 65535) {
+        HIPCHK(launch_init_tt_batch(L, ctx->d_T, ctx->d_starts, nstart, ctx->stream));
+        HIPCHK(launch_init_tile_flags_batch(L, ctx->d_tile_flags, (long long)flag_words(L, ctx->kernel), ctx->d_starts, nstart,
+                                            ctx->plans[np - 1].ra, np, ctx->stream));
+    }
     HIPCHK(hipMemcpyAsync(ctx->d_active, ctx->h_active, nstart * sizeof(int),
                           hipMemcpyHostToDevice, ctx->stream));
     HIPCHK(hipMemsetAsync(ctx->d_work, 0, 3 * nstart * sizeof(unsigned long long), ctx->stream));
@@ -523,8 +549,18 @@ int solve_device_body(ttsweep_ctx *ctx, int nstart, const ttsweep_start *starts,
         if (build_worklist(ctx, nactive)) return -1;
     }
 
-    for (int s = 0; s < nstart; s++)
-        HIPCHK(launch_unpack(L, ctx->h_starts[s].T, tt_dev[s], ctx->stream));
+    if (ctx->kernel == TTSWEEP_KERNEL_STRIP && nstart <= 65535 && nstart > 1) {
+        // (all boxes in one launch; the boxes' addresses go through the pinned copy of the "changed" words,
+        // which the driver loop is done with: PASS_SLOTS + 1 ints per start hold a pointer per start)
+        float **const hp = reinterpret_cast<float **>(ctx->h_changed);
+        float **const dp = reinterpret_cast<float **>(ctx->d_changed);
+        for (int s = 0; s < nstart; s++) hp[s] = tt_dev[s];
+        HIPCHK(hipMemcpyAsync(dp, hp, nstart * sizeof(float *), hipMemcpyHostToDevice, ctx->stream));
+        HIPCHK(launch_unpack_batch(L, ctx->d_T, dp, nstart, ctx->stream));
+    } else {
+        for (int s = 0; s < nstart; s++)
+            HIPCHK(launch_unpack(L, ctx->h_starts[s].T, tt_dev[s], ctx->stream));
+    }
     if (ctx->kernel == TTSWEEP_KERNEL_TILE)
         HIPCHK(launch_tile_reduce_work(ctx->d_tile_wgwork, ctx->tile_blocks, nstart, ctx->d_work, ctx->stream));
     HIPCHK(hipMemcpyAsync(ctx->h_work, ctx->d_work, 3 * nstart * sizeof(unsigned long long),

@@ -17,6 +17,11 @@ hipError_t launch_unpack(const DevLayout &L, const float *padded, float *user,
 hipError_t launch_init_tt(const DevLayout &L, float *padded, long long sidx,
                           hipStream_t st);
 
+// the same for all starts of a solve in one launch each: volume s at T0 + s * L.cells (L.cells % 4 == 0), start
+// cell starts[s].sidx; users[s] = device address of box s (a device array)
+hipError_t launch_init_tt_batch(const DevLayout &L, float *T0, const StartDesc *starts, int nstart, hipStream_t st);
+hipError_t launch_unpack_batch(const DevLayout &L, const float *padded0, float *const *users, int nstart, hipStream_t st);
+
 // ---- device census / input check -------------------------------------------
 // *seen |= 1 << (XCD id) for every workgroup of an `nblocks`-workgroup launch
 hipError_t launch_xcc_census(unsigned *seen, int nblocks, hipStream_t st);
@@ -79,6 +84,11 @@ hipError_t launch_flush_deferred(const DevLayout &L, int np, int *flags0, long l
 // the star along the plane axis and the planes per unit of the solve.)
 hipError_t launch_init_tile_flags(const DevLayout &L, const StartDesc &sd, bool from_box, int ra, int np,
                                   hipStream_t st);
+
+// ... for all starts of a solve at once (fresh boxes: the start's patch is the only source); start s's words at
+// flags0 + s * stride
+hipError_t launch_init_tile_flags_batch(const DevLayout &L, int *flags0, long long stride, const StartDesc *starts,
+                                        int nstart, int ra, int np, hipStream_t st);
 
 // ---- sweep, variant TILE ---------------------------------------------------
 // One call = the tiles of one hyperplane of an ordering sweep (TileSweep), ONE kernel: a grid of

@@ -109,7 +109,45 @@ unpack_rows_kernel(DevLayout L, const float *__restrict__ padded, float *__restr
         *reinterpret_cast<const float4 *>(padded + dev_index(L, a, b, c));
 }
 
+// The same for every start of a solve in ONE launch (blockIdx.y = start): a launch per start and kernel
+// was 1.2 ms of small, serialised kernels around the 24-start solve.
+__global__ void __launch_bounds__(256)
+init_tt_batch_kernel(long long cells, float *__restrict__ T0, const StartDesc *__restrict__ starts)
+{
+    const long long idx4 = (long long)blockIdx.x * 256 + threadIdx.x;     // float4 of a padded volume
+    if (4 * idx4 >= cells) return;
+    const long long sidx = starts[blockIdx.y].sidx;
+    const float inf = __builtin_inff();
+    float4 val = make_float4(inf, inf, inf, inf);
+    if ((sidx >> 2) == idx4) reinterpret_cast<float *>(&val)[sidx & 3] = 0.0f;
+    reinterpret_cast<float4 *>(T0 + (long long)blockIdx.y * cells)[idx4] = val;
+}
+
+__global__ void __launch_bounds__(256)
+unpack_batch_kernel(DevLayout L, const float *__restrict__ padded0, float *const *__restrict__ users)
+{
+    long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= L.cells) return;
+    int a, b, c;
+    padded_coords(L, idx, a, b, c);
+    if (interior(L, a, b, c)) users[blockIdx.y][user_index(L, a, b, c)] = padded0[(long long)blockIdx.y * L.cells + idx];
+}
+
 static inline unsigned blocks_for(long long n, int per) { return (unsigned)((n + per - 1) / per); }
+
+hipError_t launch_init_tt_batch(const DevLayout &L, float *T0, const StartDesc *starts, int nstart, hipStream_t st)
+{
+    if (nstart <= 0 || L.cells % 4 != 0 || nstart > 65535) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(init_tt_batch_kernel, dim3(blocks_for(L.cells / 4, 256), nstart), dim3(256), 0, st, L.cells, T0, starts);
+    return hipGetLastError();
+}
+
+hipError_t launch_unpack_batch(const DevLayout &L, const float *padded0, float *const *users, int nstart, hipStream_t st)
+{
+    if (nstart <= 0 || nstart > 65535) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(unpack_batch_kernel, dim3(blocks_for(L.cells, 256), nstart), dim3(256), 0, st, L, padded0, users);
+    return hipGetLastError();
+}
 
 static bool rows_vectorisable(const DevLayout &L, const void *user, const void *padded)
 {
@@ -666,7 +704,37 @@ init_tile_flags_box_kernel(DevLayout L, const float *__restrict__ T, int *__rest
 }
 
 __global__ void seed_pend_kernel(DevLayout L, int *__restrict__ tile_flags, int nflag, int ra, int np, int btiles,
-                                 int cstrips, int nunits);      // (below, next to push_improved)
+                                 int cstrips, int nunits, long long stride);      // (below, next to push_improved)
+
+// init_tile_flags_kernel for every start of a solve (blockIdx.y = start; flags0 + start * stride)
+__global__ void __launch_bounds__(256)
+init_tile_flags_batch_kernel(int *__restrict__ flags0, long long stride, int nflag, const StartDesc *__restrict__ starts,
+                             int btiles, int cstrips)
+{
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= nflag) return;
+    int *const flags = flags0 + (long long)blockIdx.y * stride;
+    const int sa = starts[blockIdx.y].sa, sb = starts[blockIdx.y].sb, sc = starts[blockIdx.y].sc;
+    const int start_flag = (sa * btiles + sb / STRIP_TB) * cstrips + sc / STRIP_K;
+    flags[t] = 0;
+    flags[nflag + t] = t == start_flag ? FLAG_ALL : 0;
+    flags[2 * nflag + t] = 0;
+    if (t == 0) flags[3 * nflag] = 1;
+}
+
+hipError_t launch_init_tile_flags_batch(const DevLayout &L, int *flags0, long long stride, const StartDesc *starts,
+                                        int nstart, int ra, int np, hipStream_t st)
+{
+    if (nstart <= 0 || nstart > 65535) return hipErrorInvalidValue;
+    const int btiles = strip_btiles(L), cstrips = strip_cstrips(L);
+    const int nflag = strip_flag_words(L);
+    hipLaunchKernelGGL(init_tile_flags_batch_kernel, dim3((nflag + 255) / 256, nstart), dim3(256), 0, st,
+                       flags0, stride, nflag, starts, btiles, cstrips);
+    const int nunits = strip_units(L, np);
+    hipLaunchKernelGGL(seed_pend_kernel, dim3((nunits + 255) / 256, nstart), dim3(256), 0, st, L, flags0, nflag, ra, np,
+                       btiles, cstrips, nunits, stride);
+    return hipGetLastError();
+}
 
 hipError_t launch_init_tile_flags(const DevLayout &L, const StartDesc &sd, bool from_box, int ra, int np, hipStream_t st)
 {
@@ -684,7 +752,7 @@ hipError_t launch_init_tile_flags(const DevLayout &L, const StartDesc &sd, bool 
     }
     const int nunits = strip_units(L, np);
     hipLaunchKernelGGL(seed_pend_kernel, dim3((nunits + 255) / 256), dim3(256), 0, st, L, sd.tile_flags, nflag, ra, np,
-                       btiles, cstrips, nunits);
+                       btiles, cstrips, nunits, 0ll);
     return hipGetLastError();
 }
 
@@ -808,10 +876,12 @@ hipError_t launch_flush_deferred(const DevLayout &L, int np, int *flags0, long l
 // second flag block (the start's patch, or every patch that holds a finite value): one thread
 // per unit, the rule of push_improved read backwards.
 __global__ void __launch_bounds__(256)
-seed_pend_kernel(DevLayout L, int *__restrict__ tile_flags, int nflag, int ra, int np, int btiles, int cstrips, int nunits)
+seed_pend_kernel(DevLayout L, int *__restrict__ tile_flags, int nflag, int ra, int np, int btiles, int cstrips, int nunits,
+                 long long stride)
 {
     const int unit = blockIdx.x * 256 + threadIdx.x;
     if (unit >= nunits) return;
+    tile_flags += (long long)blockIdx.y * stride;       // (one launch for all starts of a solve: blockIdx.y = start)
     int u = unit;
     const int cs = u % cstrips;  u /= cstrips;
     const int bt = u % btiles;   u /= btiles;
