@@ -526,6 +526,8 @@ def main():
                        "starts_per_gpu": len(mine), "parallelism": f"starts sharded over {world} GPU(s)",
                        "gather": gather,
                        "kernel_variant": st["kernel_variant"],
+                       "driver": ("one launch per solve (ring planners + workers, convergence detected on the device)"
+                                  if st["kernel_variant"] == 2 and st["launches"] == 1 else "a launch (pair) per pass / hyperplane, convergence tested on the host"),
                        "library": os.path.relpath(P._lib.LIB_PATH, ROOT),
                        "passes_per_start_mean": sweeps_all / args.steps / nstart,
                        "full_sweep_equivalents_per_start_mean": relaxed_all / cells / args.steps / nstart},
