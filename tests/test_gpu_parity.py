@@ -733,6 +733,35 @@ def test_one_launch_solve_that_gives_up_is_finished_by_the_pass_driver(P, full):
         assert hashlib.sha256(tt.tobytes()).hexdigest() == want, start
 
 
+@pytest.mark.parametrize("nstart", [255, 256])
+def test_many_starts_on_a_small_grid(P, nstart):
+    """255 starts are the most a one-launch solve takes (eight rings of up to 32 starts; a ring entry holds the
+    start in 8 bits), 256 go to the pass driver: both against the CELL kernel, bit for bit, duplicates and
+    corner starts included."""
+    rng = np.random.default_rng(77)
+    shape = (21, 18, 12)
+    v = rng.uniform(0.2, 1.0, size=shape).astype(np.float32)
+    fs = P.inputs.make_fs(P.inputs.read_triples(P.inputs.star_path("5")))
+    starts = np.stack([rng.integers(0, n, size=nstart) for n in shape], axis=1).astype(np.int32)
+    starts[0] = (0, 0, 0)
+    starts[1] = (20, 17, 11)
+    starts[2] = starts[3]
+
+    def fresh():
+        out = []
+        for st in starts:
+            t = np.full(shape, np.inf, np.float32)
+            t[tuple(st)] = 0
+            out.append(t)
+        return out
+
+    ref, _, _ = gpu_converge(P, v, fs, starts, tts=fresh(), kernel=1)
+    got, rc, st = gpu_converge(P, v, fs, starts, tts=fresh(), kernel=2)
+    assert rc == 1 and st["kernel_variant"] == 2 and (st["launches"] == 1) == (nstart <= 255)
+    for a, b in zip(got, ref):
+        assert_bit_equal(a, b, f"{nstart} starts")
+
+
 def test_converged_box_with_one_finite_unit_reports_no_change(P, oracle):
     """A star that only moves along z reaches one z-column: every finite cell sits in ONE
     activity unit, which is exactly the case the distance gate treats as "grown from one
