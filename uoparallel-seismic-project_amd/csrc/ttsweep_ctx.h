@@ -98,6 +98,7 @@ struct ttsweep_ctx {
     // STRIP: bits for units nearer to the start than the improved cells by more than this many cells are
     // deferred until the start is otherwise at rest (push_improved); < -1e30: off
     float defer_margin = 1.f;
+    bool defer_suspended = false;           // (pass driver) the solve in progress has flushed once: no more deferral
     // STRIP, one launch per solve (AsyncSolve, ttsweep_dev.h)
     int async_mode = -1;                    // TTSWEEP_OPT_ASYNC
     int async_low = 0, async_high = 0;      // 0: defaults (solve_async_strip)

@@ -167,7 +167,8 @@ constexpr unsigned ASYNC_BUSY = 0x80000000u;            // pend word: the unit i
 constexpr unsigned ASYNC_UNIT_SPECIAL = 0xfffffu;       // ring entry: relax the start's dead-edge cells
 constexpr unsigned long long ASYNC_EXIT = ~0ull;
 constexpr int ASYNC_MAX_STARTS = 255;                   // (8 bits of a ring entry; 255 keeps ASYNC_EXIT apart)
-// ring entry: planes (16) | unit (20) << 16 | start (8) << 36 | position in the ring mod 2^20 << 44
+// ring entry: planes (16) | unit (20) << 16 | start (8) << 36 | position in the ring mod 2^19 << 44 | "tell
+// every unit at once" << 63 (set from the ring's first flush of deferred bits on)
 enum : int { ASYNC_OK = 0, ASYNC_ERR_TIMEOUT = 1, ASYNC_ERR_CAP = 2 };
 
 struct AsyncSolve {

@@ -53,7 +53,7 @@ static int launch_pass_strip(ttsweep_ctx *ctx, int nactive, int nstart, int *d_c
     tail.nstart = nstart;
     tail.changed_host = h_changed_slot;
     tail.changed_next = d_changed_next;
-    tail.defer_margin = ctx->defer_margin;
+    tail.defer_margin = ctx->defer_suspended ? -3.0e38f : ctx->defer_margin;
     HIPCHK(launch_sweep_units(ctx->L, ctx->d_v, ctx->d_starts, ctx->d_unitq, (int)ctx->unitq_cap,
                               ctx->nlists, ctx->d_unitq_ctrl, ctx->unitq_blocks, d_changed,
                               ctx->d_strip_items[ctx->np - 1], plan, tail, ctx->stream));
@@ -405,6 +405,7 @@ int solve_device_body(ttsweep_ctx *ctx, int nstart, const ttsweep_start *starts,
                           hipMemcpyHostToDevice, ctx->stream));
     HIPCHK(hipMemsetAsync(ctx->d_work, 0, 3 * nstart * sizeof(unsigned long long), ctx->stream));
     ctx->pass_index = 0;
+    ctx->defer_suspended = false;
     ctx->tile_epoch = 1;
     if (ctx->kernel == TTSWEEP_KERNEL_TILE && prepare_tile_sweep(ctx)) return -1;
     bool async = use_async(ctx, nstart);
@@ -545,6 +546,7 @@ int solve_device_body(ttsweep_ctx *ctx, int nstart, const ttsweep_start *starts,
         for (int s = 0; s < nstart; s++)
             if (hfl[s]) { ctx->h_active[nactive++] = s; done[s] = 0; }
         if (nactive == 0) break;
+        ctx->defer_suspended = true;        // (one flush per solve: from here on every unit is told at once)
         HIPCHK(hipMemcpyAsync(ctx->d_active, ctx->h_active, nactive * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
         if (build_worklist(ctx, nactive)) return -1;
     }

@@ -1203,6 +1203,10 @@ __device__ __forceinline__ void async_planner(const DevLayout &L, const StartDes
     // whether the ring was at rest when it began, whether it met a word that was not zero
     int base = n, round = -1, activity = 0;
     bool quiet = false, from_zero = true;
+    // bit 63 of the entries published from the first flush of deferred bits on: the workers then tell every unit
+    // at once.  If the geometry misled (the late relaxations improved cells), what follows is an ordinary solve
+    // from a good state, not a chain of deferrals and flushes.
+    unsigned long long nodefer = 0ull;
     float gate_r2 = 3.0e38f, gate_r = as.gate_r0;
 
     // publishes the dead-edge entries of the ring's starts whose counter has reached `threshold`
@@ -1215,7 +1219,7 @@ __device__ __forceinline__ void async_planner(const DevLayout &L, const StartDes
                 const unsigned pos = t + (unsigned)__popcll(bal & ((1ull << lane) - 1ull));
                 const unsigned long long e = 0xffffull | ((unsigned long long)ASYNC_UNIT_SPECIAL << 16)
                                            | ((unsigned long long)rstarts[lane] << 36)
-                                           | ((unsigned long long)(pos & 0xfffffu) << 44);
+                                           | ((unsigned long long)(pos & 0x7ffffu) << 44) | nodefer;
                 __hip_atomic_store(ents + (pos & (unsigned)as.cap_mask), e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 dirty[lane] = 0;
             }
@@ -1354,7 +1358,7 @@ __device__ __forceinline__ void async_planner(const DevLayout &L, const StartDes
                 if (planes[k] != 0u) {
                     const unsigned pos = t + (unsigned)(off[k] + rank[k]);
                     const unsigned long long e = (unsigned long long)planes[k] | ((unsigned long long)(unsigned)uu[k] << 16)
-                                               | ((unsigned long long)s << 36) | ((unsigned long long)(pos & 0xfffffu) << 44);
+                                               | ((unsigned long long)s << 36) | ((unsigned long long)(pos & 0x7ffffu) << 44) | nodefer;
                     __hip_atomic_store(ents + (pos & (unsigned)as.cap_mask), e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     atomicAdd(&dirty[ss[k] >> 16], 1);
                     int u = uu[k];
@@ -1410,6 +1414,7 @@ __device__ __forceinline__ void async_planner(const DevLayout &L, const StartDes
                     if (tid == 0) atomicOr(ht, 1ull << 63);
                     return;
                 }
+                nodefer = 1ull << 63;
             }
             t += (unsigned)sp;
         } else {
@@ -1434,7 +1439,7 @@ __device__ __forceinline__ unsigned long long async_claim(const AsyncSolve &as, 
                 const unsigned long long *slot = as.entries + (size_t)q * (size_t)(as.cap_mask + 1) + (j & (unsigned)as.cap_mask);
                 for (unsigned spin2 = 0;; spin2++) {
                     const unsigned long long e = ald64(slot);
-                    if ((unsigned)(e >> 44) == (j & 0xfffffu)) { *ring = q; return e; }
+                    if (((unsigned)(e >> 44) & 0x7ffffu) == (j & 0x7ffffu)) { *ring = q; return e; }
                     // not published (yet): somebody else was faster and position j lies beyond the tail
                     const unsigned long long y = ald64(ht);
                     if ((y >> 63) && (int)(j - ((unsigned)(y >> 32) & 0x7fffffffu)) >= 0) break;   // ... and never will be
@@ -1541,6 +1546,7 @@ sweep_units_kernel(DevLayout L, const float *__restrict__ v, const StartDesc *__
         PROF_T(t_top);
         int s, my_unit, q;
         unsigned my_planes;
+        float defer_margin = tail.defer_margin;
         if (ASYNC) {
             // a ring entry; what it stands for was released by its producers before the planner
             // could see their bits: acquire before anything of it is loaded
@@ -1561,11 +1567,12 @@ sweep_units_kernel(DevLayout L, const float *__restrict__ v, const StartDesc *__
             my_planes = e_lo & 0xffffu;
             my_unit = (int)((e_lo >> 16) | ((e_hi & 0xfu) << 16));
             s = (int)((e_hi >> 4) & 0xffu);
+            defer_margin = (e_hi >> 31) ? -3.0e38f : tail.defer_margin;     // (entries after the ring's first flush)
             if ((unsigned)my_unit == ASYNC_UNIT_SPECIAL) {
                 // the dead-edge cells of start s, one wave per cell
                 const StartDesc sd = starts[s];
                 for (int cell = wave; cell < tail.max_box_cells; cell += NS)
-                    relax_special_cell<true>(L, v, sd, s, cell, changed, tail.entries, tail.nentries, plan.ra, NP, lane, tail.defer_margin);
+                    relax_special_cell<true>(L, v, sd, s, cell, changed, tail.entries, tail.nentries, plan.ra, NP, lane, defer_margin);
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 __syncthreads();
                 if (tid == 0) atomicAdd(reinterpret_cast<unsigned *>(as.ctl + (size_t)q * ASYNC_CTL_STRIDE + 16), 1u);
@@ -1770,7 +1777,7 @@ sweep_units_kernel(DevLayout L, const float *__restrict__ v, const StartDesc *__
             }
         }
         if (improved) {         // (wave-uniform) the units that stage this plane have to look again
-            const DeferRule rule{sdp->sa, sdp->sb, sdp->sc, tail.defer_margin};
+            const DeferRule rule{sdp->sa, sdp->sb, sdp->sc, defer_margin};
             push_improved<NP>(L, plan.ra, btiles, cstrips, reinterpret_cast<unsigned *>(tile_flags + 2 * nflag),
                               a, bt, cs, improved, lane, rule, reinterpret_cast<unsigned *>(tile_flags));
             // (the start's word: once per wave, start and pass - its few words are a hot spot)
