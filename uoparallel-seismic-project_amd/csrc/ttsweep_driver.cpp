@@ -182,10 +182,13 @@ static int launch_pass(ttsweep_ctx *ctx, int nactive, int nstart, int *d_changed
 }
 
 // STRIP, one launch per solve (AsyncSolve, ttsweep_dev.h): can this solve run that way, and should it?
-static bool use_async(const ttsweep_ctx *ctx, int nstart)
+static bool use_async(ttsweep_ctx *ctx, int nstart)
 {
     if (ctx->kernel != TTSWEEP_KERNEL_STRIP || ctx->async_mode == 0) return false;
     if (nstart > ASYNC_MAX_STARTS || strip_units(ctx->L, ctx->np) >= (int)ASYNC_UNIT_SPECIAL) return false;
+    // (planners take up to ASYNC_MAX_RINGS workgroups of the resident grid: a device that holds only a handful
+    // keeps the pass driver)
+    if (ensure_unit_grid(ctx) || ctx->unitq_blocks < 4 * ASYNC_MAX_RINGS) return false;
     return true;        // (-1: wherever it can run; 1: the same)
 }
 
