@@ -1181,7 +1181,8 @@ __device__ __forceinline__ void async_planner(const DevLayout &L, const StartDes
     const int *__restrict__ rstarts = as.ring_starts + as.ring_start_off[r];
     const int nflag = L.n[0] * btiles * cstrips;
     constexpr int KSCAN = 4;                    // list entries per thread and scan step
-    int *sh = lds;                              // [0] head, [1] completed, [2] stop
+    int *sh = lds;                              // [0] head, [1] completed, [2] stop, [3] dead-edge entries just published,
+                                                // [4] first list position this round met with anything to do
     int *cnt = lds + 8;                         // [KSCAN][waves] due units found
     int *dirty = lds + 8 + KSCAN * STRIP_NS;    // [ASYNC_RING_STARTS] units published since the start's last special
     int *minact = dirty + ASYNC_RING_STARTS;    // [ASYNC_RING_STARTS] smallest squared distance (float bits) met with work, this round
