@@ -1051,15 +1051,13 @@ __device__ __forceinline__ void relax_special_cell(const DevLayout &L, const flo
     for (int w = 32; w >= 1; w >>= 1) best = fminf(best, __shfl_xor(best, w));
     const bool better = best < told;        // (wave-uniform: `best` is the wave's minimum)
     if (lane == 0 && better) {
-        T[ci] = best;
+        if (ASYNC) __hip_atomic_store(&T[ci], best, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (write-through)
+        else T[ci] = best;
         atomicOr(&changed[s], CHANGED_IMPROVED);
     }
     if (better) {
-        if (ASYNC) {    // one launch per solve: the store is released before anybody is told about it
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        }
+        // (one launch per solve: the store has arrived before anybody is told about it)
+        if (ASYNC) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         const int btiles = strip_btiles(L), cstrips = strip_cstrips(L);
         unsigned *const pend = reinterpret_cast<unsigned *>(sd.tile_flags + 2 * strip_flag_words(L));
         const DeferRule rule{sd.sa, sd.sb, sd.sc, defer_margin};
@@ -1759,7 +1757,10 @@ sweep_units_kernel(DevLayout L, const float *__restrict__ v, const StartDesc *__
             const int c = c0 + cq;
             const bool special = in_box_ab && c >= box_lo2 && c <= box_hi2;
             if (row_ok && c < L.n[2] && !special && best[qq] < told[qq]) {
-                Trow[qq] = best[qq];
+                // (one launch per solve: a write-through store - global_store ... sc1 -, so that no write-back of the
+                // XCD's L2 is needed before the bits are pushed, only the wait for the stores themselves)
+                if (ASYNC) __hip_atomic_store(&Trow[qq], best[qq], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                else Trow[qq] = best[qq];
                 const int zc = 1 | (cq < STRIP_CF - 1 ? 2 : 0) | (cq > K - STRIP_CF ? 4 : 0);
                 improved |= zc | (zb_lo ? zc << 3 : 0) | (zb_hi ? zc << 6 : 0);
             }
@@ -1767,15 +1768,9 @@ sweep_units_kernel(DevLayout L, const float *__restrict__ v, const StartDesc *__
 #pragma unroll
         for (int w = 32; w >= 1; w >>= 1) improved |= __shfl_xor(improved, w);
         if (ASYNC) {
-            // every wave's stores have left it; one release for the workgroup; then the bits
+            // every wave's (write-through) stores have arrived, everybody knows it; then the bits
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            if (__syncthreads_or(improved)) {
-                if (tid == 0) {
-                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                }
-                __syncthreads();
-            }
+            __syncthreads();
         }
         if (improved) {         // (wave-uniform) the units that stage this plane have to look again
             const DeferRule rule{sdp->sa, sdp->sb, sdp->sc, defer_margin};
