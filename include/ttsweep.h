@@ -67,6 +67,9 @@ typedef struct ttsweep_stats {
                                    library's stream; 0 unless timing is enabled) */
     double solve_ms;            /* device time of the whole solve (events) */
     int kernel_variant;         /* which sweep kernel ran (TTSWEEP_KERNEL_*) */
+    int fallbacks;              /* solves whose one-launch form gave up (a wait inside it ran into its
+                                   wall-clock limit) and that the pass / hyperplane driver then finished:
+                                   the result is the same, the time is not */
 } ttsweep_stats;
 
 typedef struct ttsweep_ctx ttsweep_ctx;

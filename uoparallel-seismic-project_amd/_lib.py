@@ -46,7 +46,7 @@ class Stats(C.Structure):
                 ("cells", C.c_longlong),
                 ("relaxations_per_sweep", C.c_longlong), ("launches", C.c_longlong),
                 ("sweep_kernel_ms", C.c_double), ("solve_ms", C.c_double),
-                ("kernel_variant", C.c_int)]
+                ("kernel_variant", C.c_int), ("fallbacks", C.c_int)]
 
 
 # every symbol include/ttsweep.h declares: (name, restype, argtypes)

@@ -192,6 +192,15 @@ void ttsweep_destroy(ttsweep_ctx *ctx)
     if (ctx->h_async_status) (void)hipHostFree(ctx->h_async_status);
     (void)hipFree(ctx->d_work);
     (void)hipFree(ctx->d_tile_wgwork);
+    (void)hipFree(ctx->d_col_prog);
+    (void)hipFree(ctx->d_col_seal);
+    (void)hipFree(ctx->d_col_claim);
+    (void)hipFree(ctx->d_col_due);
+    (void)hipFree(ctx->d_col_status);
+    (void)hipFree(ctx->d_col_done);
+    (void)hipFree(ctx->d_col_seqtab);
+    if (ctx->h_col_status) (void)hipHostFree(ctx->h_col_status);
+    if (ctx->h_col_done) (void)hipHostFree(ctx->h_col_done);
     (void)hipFree(ctx->d_tile_dmin);
     if (ctx->h_tile_dmin) (void)hipHostFree(ctx->h_tile_dmin);
     (void)hipFree(ctx->d_vface);
@@ -662,6 +671,7 @@ int ttsweep_solve(ttsweep_ctx *ctx, int nstart, const ttsweep_start *starts,
         total.sweep_kernel_ms += b.sweep_kernel_ms;
         total.solve_ms += b.solve_ms;
         total.kernel_variant = b.kernel_variant;
+        total.fallbacks += b.fallbacks;
     }
     ctx->stats = total;
     return any;

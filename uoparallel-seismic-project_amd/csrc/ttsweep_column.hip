@@ -1,0 +1,581 @@
+// ttsweep_column.hip - sweep, variant TILE, plain 6-neighbour star: ONE launch per solve ("column pipelines").
+//
+// Same relaxation and the same eight orderings as ttsweep_tile.hip (serial_new/sweep-tt-multistart.c:203-249 is
+// the (+,+,+) ordering; old/wavefront-openmp/wave-multistart.c:415-530 the reference's plane orders), but the
+// driver loop (serial_new/...:151-170) runs on the device and the hyperplane launches are gone:
+//   * a COLUMN is the stack of NK tiles (8 x 8 x 32 cells each) above one tile position (I, J).  One wavefront
+//     owns a column for one ordering sweep.  Lane (i', j') walks the z-row of cell column (i', j'), ONE cell per
+//     step, i' + j' cells behind lane (0, 0): a systolic Gauss-Seidel sweep as in sixc_sweep, but the pipeline
+//     does not drain at tile boundaries - consecutive due tiles of the column are one run of 32 steps per tile
+//     (+ 14 once per run; a tile on its own is 46).  The rows live in LDS as a ring of three 16-cell chunks
+//     (64 bytes of every one of the 98 image rows, v and T): while the lanes are spread over chunks j - 1 and j,
+//     chunk j + 1 is in flight (LDS-DMA, 14 steps ahead) into the slot chunk j - 2 was written back from.
+//     Every lane address of the 48-step ring period is a register (AX[48]); a step has no address arithmetic.
+//   * Columns are claimed in sweep order - by level I' + J' of the tile position, one sequence per XCD - and
+//     wait for each other through ONE 64-bit progress word per column and start (ColumnSolve, ttsweep_dev.h):
+//     tile k of a column is staged when both upwind columns have finished their tile k of this sweep, a column
+//     starts its sweep e when it and its four neighbours have sealed sweep e - 1.  So nobody writes what a
+//     column reads while it reads it: every sweep computes exactly what the sequential ordering sweep computes.
+//     Successive sweeps overlap (sweep e + 1 follows sweep e across the grid), no launch, no host round trip.
+//   * A tile is relaxed in sweep e when it is DUE: a neighbour that comes later in the sweep order (or the tile
+//     itself) improved in an earlier sweep (bits in ColumnSolve::due), or an upwind neighbour improved in THIS
+//     sweep (the upwind columns' progress words carry the bits; inside the column the pipeline just goes on).
+//     A sweep in which no tile of a start improved leaves no bit: the start is at rest (counted per start and
+//     sweep when columns seal).
+// Visibility between workgroups (MI355X_MICROARCH.md, "inter-workgroup visibility"): travel times are stored
+// write-through (sc1), the storing wave waits for its stores (vmcnt(0)) before it publishes progress (an sc1
+// store); a wave that has read progress (sc1 loads) invalidates its L1 (buffer_inv sc1) before it stages.
+// Results: bit-identical to the reference's fixed point (every value is the length of a path and only ever
+// decreases; rest is detected only when every due tile has been relaxed against final neighbours).
+#include "ttsweep_kernels.h"
+
+#include <algorithm>
+#include <vector>
+
+namespace ttsweep {
+
+namespace {
+
+typedef __amdgpu_buffer_rsrc_t col_rsrc;
+typedef float col_f2 __attribute__((ext_vector_type(2)));
+typedef unsigned col_u4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) char *lds_char;
+
+constexpr int CS = 16;                          // cells of a chunk along z
+constexpr int CRING = 3;                        // chunks of a row the ring holds
+constexpr int CNR = (TILE_X + 2) * (TILE_Y + 2) - 2;   // image rows: 10 x 10 but the first and the last (98)
+constexpr int CROWB = CS * 4;                   // bytes of a row of a chunk
+constexpr int CSLOTB = CNR * CROWB;             // bytes of a chunk (one array)
+constexpr int CARRB = 18944;                    // the ring of one array (>= CRING * CSLOTB, whole 256-byte blocks)
+constexpr int CLDSB = 2 * CARRB;                // v ring, T ring
+constexpr int CDX = (TILE_Y + 2) * CROWB;       // from an image row to its x + 1 neighbour
+constexpr int CPER = CS * CRING;                // steps of the ring period
+constexpr int CNDMA = (CNR * (CS / 4) + 63) / 64;      // LDS-DMA wave instructions per chunk and array (7)
+constexpr int CSIG = TILE_X + TILE_Y - 2;       // largest lane skew (14)
+static_assert(TILE_X == 8 && TILE_Y == 8 && TILE_Z == 2 * CS, "column pipelines: 8 x 8 x 32 tiles");
+static_assert(CARRB >= CRING * CSLOTB && CARRB % 256 == 0, "ring size");
+
+__device__ __forceinline__ col_rsrc col_make_rsrc(const float *base)
+{
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(base), 0, 0xffffffff, 0x00020000);
+}
+__device__ __forceinline__ int cuni(int x) { return __builtin_amdgcn_readfirstlane(x); }
+template <typename T>
+__device__ __forceinline__ T *cuni_ptr(T *p)
+{
+    const unsigned long long u = reinterpret_cast<unsigned long long>(p);
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)u);
+    const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(u >> 32));
+    return reinterpret_cast<T *>(((unsigned long long)hi << 32) | lo);
+}
+__device__ __forceinline__ unsigned long long cld64(const unsigned long long *p)
+{
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ unsigned cld32(const unsigned *p)
+{
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ long long col_clock()
+{
+    unsigned long long t;
+    asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) :: "memory");
+    return (long long)t;
+}
+__device__ __forceinline__ void col_fail(const ColumnSolve &P, unsigned code)
+{
+    atomicCAS(P.status, (unsigned)COL_RUNNING, code);
+}
+__device__ __forceinline__ unsigned col_flip(unsigned m, int nk) { return __brev(m) >> (32 - nk); }
+
+// progress word: sweep << 40 | tiles finished (0xff: sealed) << 32 | improved tiles (sweep order)
+__device__ __forceinline__ unsigned col_key(int sweep, int cnt) { return ((unsigned)sweep << 8) | (unsigned)cnt; }
+
+#define CLDS_F(off) (*reinterpret_cast<__attribute__((address_space(3))) const float *>(lp + (off)))
+
+// what a lane carries from step to step (lateral neighbours in the pairs the LDS delivers them in: ds_read2_b32)
+struct ColRegs {
+    float vc, tc;               // the cell of this step
+    float vn, tn;               // the next cell of the row (z-downwind neighbour)
+    float vzu, tzu;             // the previous cell: its velocity, its result (z-upwind neighbour)
+    col_f2 va, vb;              // velocities of the lateral neighbours of this step: (x-, y-), (y+, x+)
+};
+
+struct ColConst {
+    col_f2 ha, hb;              // d / 2 of (x-, y-), (y+, x+)
+    float hzu, hzd;             // ... of the z-upwind and the z-downwind entry
+    int sigact;                 // the lane's skew i' + j', or a huge number when its cell column lies outside the grid
+};
+
+// One step: every lane relaxes one cell against its six neighbours.  Of its inputs only the travel times of the
+// four lateral neighbours can have been written in the previous step (by the two upwind lanes): they are read
+// first, behind that write; everything else arrived during the previous steps.
+template <int N>
+__device__ __forceinline__ void col_step(const lds_char lp, const int (&AX)[CPER], ColRegs &r, const ColConst &c, const int tb,
+                                         const unsigned span, unsigned long long &imp)
+{
+    constexpr int N1 = (N + 1) % CPER, N2 = (N + 2) % CPER;
+    const int a0 = AX[N], a1 = AX[N1], a2 = AX[N2];
+    col_f2 ta, tb2, nva, nvb;
+    ta.x = CLDS_F(a0 + CARRB);                  ta.y = CLDS_F(a0 + CARRB + CDX - CROWB);
+    tb2.x = CLDS_F(a0 + CARRB + CDX + CROWB);   tb2.y = CLDS_F(a0 + CARRB + 2 * CDX);
+    nva.x = CLDS_F(a1);                         nva.y = CLDS_F(a1 + CDX - CROWB);
+    nvb.x = CLDS_F(a1 + CDX + CROWB);           nvb.y = CLDS_F(a1 + 2 * CDX);
+    const float vnn = CLDS_F(a2 + CDX), tnn = CLDS_F(a2 + CARRB + CDX);
+    const col_f2 vc2 = {r.vc, r.vc};
+    const col_f2 la = c.ha * (vc2 + r.va), lb = c.hb * (vc2 + r.vb);
+    const float czu = c.hzu * (r.vc + r.vzu) + r.tzu;
+    const float czd = c.hzd * (r.vc + r.vn) + r.tn;
+    const float pre = fminf(r.tc, fminf(czu, czd));
+    const col_f2 ca = la + ta, cb = lb + tb2;
+    float best = fminf(fminf(pre, fminf(ca.x, ca.y)), fminf(cb.x, cb.y));
+    const bool act = (unsigned)(tb + (N % CS) - c.sigact) < span;      // (tb: the block's first step less the first cell)
+    best = act ? best : r.tc;
+    imp |= __ballot(best < r.tc);
+    *reinterpret_cast<__attribute__((address_space(3))) float *>(lp + a0 + CARRB + CDX) = best;
+    r.vzu = r.vc; r.tzu = best;
+    r.vc = r.vn; r.tc = r.tn;
+    r.vn = vnn; r.tn = tnn;
+    r.va = nva; r.vb = nvb;
+    __builtin_amdgcn_sched_barrier(0);
+}
+
+template <int N0, int CNT>
+struct ColSteps {
+    static __device__ __forceinline__ void run(const lds_char lp, const int (&AX)[CPER], ColRegs &r, const ColConst &c,
+                                               const int tb, const unsigned span, unsigned long long &imp)
+    {
+        col_step<N0>(lp, AX, r, c, tb, span, imp);
+        ColSteps<N0 + 1, CNT - 1>::run(lp, AX, r, c, tb, span, imp);
+    }
+};
+template <int N0>
+struct ColSteps<N0, 0> {
+    static __device__ __forceinline__ void run(const lds_char, const int (&)[CPER], ColRegs &, const ColConst &, const int,
+                                               const unsigned, unsigned long long &) {}
+};
+
+// chunk (v and T) -> ring slot SLOT: 7 LDS-DMA wave instructions per array, 64 float4 each (the last one 8)
+template <int SLOT>
+__device__ __forceinline__ void col_stage(const lds_char lp, const float *vsrc, const float *tsrc, const unsigned (&goff)[CNDMA],
+                                          const int lane)
+{
+    const col_rsrc rv = col_make_rsrc(vsrc), rt = col_make_rsrc(tsrc);
+#pragma unroll
+    for (int q = 0; q < CNDMA; q++) {
+        if (q < CNDMA - 1 || lane < (CNR * (CS / 4)) % 64) {
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rv, (__attribute__((address_space(3))) void *)(lp + SLOT * CSLOTB + q * 1024),
+                                                     16, (int)goff[q], 0, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rt, (__attribute__((address_space(3))) void *)(lp + CARRB + SLOT * CSLOTB + q * 1024),
+                                                     16, (int)goff[q], 0, 0, 0);
+        }
+    }
+}
+
+// the 64 interior rows of the T chunk in ring slot SLOT -> the volume (write-through: sc1)
+template <int SLOT>
+__device__ __forceinline__ void col_writeback(const lds_char lp, float *tdst, const unsigned (&wbg)[4], const int (&wbl)[4])
+{
+    const col_rsrc rt = col_make_rsrc(tdst);
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const col_u4 x = *reinterpret_cast<__attribute__((address_space(3))) const col_u4 *>(lp + wbl[k] + SLOT * CSLOTB);
+        __builtin_amdgcn_raw_buffer_store_b128(x, rt, (int)wbg[k], 0, 16 /* sc1 */);
+    }
+}
+
+struct ColWork {
+    unsigned long long cells = 0, tiles = 0;
+    int s = -1;                 // the start this lane counts for (lane == s % 64)
+};
+__device__ __forceinline__ void col_work_flush(const ColumnSolve &P, ColWork &w)
+{
+    if (w.s >= 0 && w.tiles) {
+        unsigned long long *const slot = P.wgwork + ((size_t)blockIdx.x * P.nstart + w.s) * 2;
+        slot[0] += w.cells * 6ull;
+        slot[1] += w.tiles;
+    }
+    w.cells = 0; w.tiles = 0;
+}
+__device__ __forceinline__ void col_work_add(const ColumnSolve &P, ColWork &w, int s, unsigned long long cells, unsigned tiles, int lane)
+{
+    if (lane == (s & 63)) {
+        if (w.s != s) { col_work_flush(P, w); w.s = s; }
+        w.cells += cells;
+        w.tiles += tiles;
+    }
+}
+
+// Lanes 0 .. 4 poll one progress word each (pa; !valid: nothing to wait for) until its key reaches `need`.
+// false: the solve is over for this column (the start is at rest, the solve has failed or ended).
+__device__ __forceinline__ bool col_poll(const ColumnSolve &P, const unsigned long long *pa, bool valid, unsigned need,
+                                         unsigned long long &pv, int s, long long deadline)
+{
+    for (unsigned spin = 0;; spin++) {
+        pv = valid ? cld64(pa) : ~0ull;
+        const bool ok = !valid || (unsigned)(pv >> 32) >= need;
+        if (__ballot(!ok) == 0ull) return true;
+        if ((spin & 3u) == 3u) {
+            if (cld32(P.status) != COL_RUNNING) return false;
+            if (cld32(reinterpret_cast<const unsigned *>(P.done + s)) != 0u) return false;
+            if (col_clock() > deadline) { col_fail(P, COL_ERR_TIMEOUT); return false; }
+        }
+        __builtin_amdgcn_s_sleep(4);
+    }
+}
+
+// what the progress words of the two upwind columns (lanes 1 and 2: pv) say about sweep e
+__device__ __forceinline__ void col_upwind(unsigned long long pv, bool valid, int e, int NK, int &known, unsigned &mask)
+{
+    const int sw = (int)(pv >> 40), cn = (int)((pv >> 32) & 0xffu);
+    int c = NK;
+    unsigned m = 0;
+    if (valid) {
+        c = sw == e ? min(cn, NK) : (sw > e ? NK : 0);
+        m = sw == e ? (unsigned)pv : 0u;
+    }
+    const int c1 = __builtin_amdgcn_readlane(c, 1), c2 = __builtin_amdgcn_readlane(c, 2);
+    known = min(c1, c2);
+    mask = (unsigned)__builtin_amdgcn_readlane((int)m, 1) | (unsigned)__builtin_amdgcn_readlane((int)m, 2);
+}
+
+} // namespace
+
+__global__ void __launch_bounds__(64)
+column_solve_kernel(const ColumnSolve P)
+{
+    extern __shared__ __attribute__((aligned(256))) char col_lds[];
+    const lds_char lp = (lds_char)col_lds;
+    const int lane = threadIdx.x;
+    const DevLayout &L = P.L;
+    const long long clock0 = col_clock();
+    const long long deadline = clock0 + P.timeout_ticks;
+    const int ncol = P.NI * P.NJ;
+
+    // per-lane constants of the staging and write-back instructions (image coordinates: the same for every ordering)
+    unsigned goff[CNDMA];
+#pragma unroll
+    for (int q = 0; q < CNDMA; q++) {
+        const int sidx = 64 * q + lane, r = sidx >> 2, quad = sidx & 3;
+        const int ri = (r + 1) / (TILE_Y + 2), rj = (r + 1) % (TILE_Y + 2);        // padded image coordinates 0 .. 9
+        goff[q] = (unsigned)(((long long)ri * L.s0 + (long long)rj * L.s1) * 4 + quad * 16);
+    }
+    unsigned wbg[4];
+    int wbl[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const int sidx = 64 * k + lane, ir = sidx >> 2, quad = sidx & 3, ci = ir >> 3, cj = ir & 7;
+        wbg[k] = (unsigned)(((long long)(ci + 1) * L.s0 + (long long)(cj + 1) * L.s1) * 4 + quad * 16);
+        wbl[k] = CARRB + ((ci + 1) * (TILE_Y + 2) + cj) * CROWB + quad * 16;
+    }
+
+    const int seq = cuni((int)blockIdx.x % P.nseq);
+    const int seqlen = P.seq_len[seq];
+    const int *const seqtab = P.seqtab + P.seq_off[seq];
+    const long long per = (long long)seqlen * P.nstart;         // entries of one sweep in this sequence
+
+    int cur_o = -1;
+    int AX[CPER];
+    int ci = 0, cj = 0, sig = 0;
+    ColConst cc{};
+    ColWork work;
+
+    for (;;) {
+        if (cld32(P.status) != COL_RUNNING) break;
+        // ---- claim the next column of this sequence
+        unsigned long long q = 0;
+        if (lane == 0) q = atomicAdd(P.claim + seq * 16, 1ull);
+        q = ((unsigned long long)(unsigned)cuni((int)(q >> 32)) << 32) | (unsigned)cuni((int)(unsigned)q);
+        const long long qs = (long long)(q / (unsigned long long)per);
+        const int rem = (int)(q - (unsigned long long)qs * (unsigned long long)per);
+        if (qs >= COL_MAX_SWEEPS - 2) { col_fail(P, COL_ERR_CAP); break; }
+        const int e = 1 + (int)qs;                              // sweep, 1-based
+        const int pos = rem / P.nstart, s = rem - pos * P.nstart;
+        if (cld32(reinterpret_cast<const unsigned *>(P.done + s)) != 0u) continue;
+        const int packed = seqtab[pos];
+        const int ip = packed & 0xffff, jp = packed >> 16;
+        const int o = (e - 1) & 7;
+        const int sx = (o & 1) ? -1 : 1, sy = (o & 2) ? -1 : 1, sz = (o & 4) ? -1 : 1;
+        const int I = sx > 0 ? ip : P.NI - 1 - ip, J = sy > 0 ? jp : P.NJ - 1 - jp;
+        if (o != cur_o) {
+            cur_o = o;
+            const int li = lane >> 3, lj = lane & 7;
+            ci = sx > 0 ? li : TILE_X - 1 - li;
+            cj = sy > 0 ? lj : TILE_Y - 1 - lj;
+            sig = li + lj;
+            const int rxm = ci * (TILE_Y + 2) + cj;             // image row of the x - 1 neighbour (own row: + CDX)
+#pragma unroll
+            for (int n = 0; n < CPER; n++) {
+                const int wq = n - sig + (n < sig ? CPER : 0);
+                const int slot = wq >> 4, zc = wq & (CS - 1);
+                AX[n] = slot * CSLOTB + rxm * CROWB + (sz > 0 ? zc : CS - 1 - zc) * 4;
+            }
+            cc.ha = col_f2{P.h[0], P.h[1]};
+            cc.hb = col_f2{P.h[4], P.h[5]};
+            cc.hzu = sz > 0 ? P.h[2] : P.h[3];
+            cc.hzd = sz > 0 ? P.h[3] : P.h[2];
+        }
+        cc.sigact = (I * TILE_X + ci < L.n[0] && J * TILE_Y + cj < L.n[1]) ? sig : 0x3fffffff;
+
+        // ---- the progress words of this column (lane 0), its upwind (1, 2) and downwind (3, 4) neighbours
+        unsigned long long *const prog = P.prog + (size_t)s * ncol;
+        const int col = I * P.NJ + J;
+        int ncolumn = col;
+        bool valid = lane == 0;
+        if (lane == 1) { valid = ip > 0; ncolumn = (I - sx) * P.NJ + J; }
+        if (lane == 2) { valid = jp > 0; ncolumn = I * P.NJ + (J - sy); }
+        if (lane == 3) { valid = ip < P.NI - 1; ncolumn = (I + sx) * P.NJ + J; }
+        if (lane == 4) { valid = jp < P.NJ - 1; ncolumn = I * P.NJ + (J + sy); }
+        if (!valid) ncolumn = col;
+        const unsigned long long *const pa = prog + ncolumn;
+        unsigned long long pv = 0;
+        // nobody is still in sweep e - 1 around this column
+        if (!col_poll(P, pa, valid && lane < 5, col_key(e - 1, 0xff), pv, s, deadline)) continue;
+        if (e > P.max_sweeps) { col_fail(P, COL_ERR_CAP); break; }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        const bool upvalid = valid && (lane == 1 || lane == 2);
+        int known_up = 0;
+        unsigned upmask = 0;
+        col_upwind(pv, upvalid, e, P.NK, known_up, upmask);
+
+        // the tiles that are due from earlier sweeps (absolute K -> sweep order)
+        unsigned mask0 = 0;
+        if (lane == 0) mask0 = atomicExch(P.due + (size_t)s * ncol + col, 0u);
+        mask0 = (unsigned)cuni((int)mask0);
+        if (sz < 0) mask0 = col_flip(mask0, P.NK);
+
+        const long long colbase = (long long)(I * TILE_X) * L.s0 + (long long)(J * TILE_Y) * L.s1 + L.lo[2];
+        const float *const vcol = P.v + colbase;
+        float *const tcol = P.T0 + (long long)s * L.cells + colbase;
+        const int dx = min(TILE_X, L.n[0] - I * TILE_X), dy = min(TILE_Y, L.n[1] - J * TILE_Y);
+
+        unsigned mymask = 0, pend = 0;      // improved tiles; tiles made due by a late improvement below them
+        int published = 0;
+        bool alive = true;
+        int k = 0;
+        while (k < P.NK) {
+            if (known_up <= k) {
+                // the upwind columns have not finished tile k: tell what is done here, then wait for them
+                if (published < k) {
+                    if (lane == 0) __hip_atomic_store(prog + col, ((unsigned long long)col_key(e, k) << 32) | mymask,
+                                                      __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    published = k;
+                }
+                if (!col_poll(P, pa, upvalid, col_key(e, k + 1), pv, s, deadline)) { alive = false; break; }
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                col_upwind(pv, upvalid, e, P.NK, known_up, upmask);
+            }
+            const unsigned avail = known_up >= 32 ? ~0u : ((1u << known_up) - 1u);
+            const unsigned dm = (mask0 | upmask | pend) & avail & ~((1u << k) - 1u);
+            if (dm == 0u) { k = known_up; continue; }
+            const int k0 = __builtin_ctz(dm);
+            if (published < k0) {
+                if (lane == 0) __hip_atomic_store(prog + col, ((unsigned long long)col_key(e, k0) << 32) | mymask,
+                                                  __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                published = k0;
+            }
+
+            // ================= a run: tiles k0, k0 + 1, ... of the column as one pipeline =================
+            // relative cell w of lane sigma at step t: w = t - sigma; chunk cr = w >> 4 lives in ring slot cr mod 3
+            auto zlo = [&](int cr) { return sz > 0 ? TILE_Z * k0 + CS * cr : TILE_Z * (P.NK - k0) - CS * (cr + 1); };
+            int wend = TILE_Z;                                  // cells of the run (grows while the tiles go on being due)
+            // cells of the run that lie inside the grid: wlo <= w < whi
+            const int wlo = sz > 0 ? 0 : max(TILE_Z * (P.NK - k0) - L.n[2], 0);
+            auto whi = [&]() { return sz > 0 ? min(wend, L.n[2] - TILE_Z * k0) : wend; };
+            col_stage<2>(lp, cuni_ptr(vcol + zlo(-1)), cuni_ptr(tcol + zlo(-1)), goff, lane);
+            col_stage<0>(lp, cuni_ptr(vcol + zlo(0)), cuni_ptr(tcol + zlo(0)), goff, lane);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            ColRegs r;
+            r.vzu = CLDS_F(AX[CPER - 1] + CDX); r.tzu = CLDS_F(AX[CPER - 1] + CARRB + CDX);
+            r.vc = CLDS_F(AX[0] + CDX); r.tc = CLDS_F(AX[0] + CARRB + CDX);
+            r.vn = CLDS_F(AX[1] + CDX); r.tn = CLDS_F(AX[1] + CARRB + CDX);
+            r.va.x = CLDS_F(AX[0]); r.va.y = CLDS_F(AX[0] + CDX - CROWB);
+            r.vb.x = CLDS_F(AX[0] + CDX + CROWB); r.vb.y = CLDS_F(AX[0] + 2 * CDX);
+
+            bool imp1 = false, imp2 = false;    // a cell improved in block j - 1 / j - 2
+            bool late = false;                  // ... after the run had been closed
+            bool closed = false;
+            unsigned tilebits = 0;              // tiles of the run that improved (bit: tile index in the run)
+            int pub_pending = -1;               // tiles finished (absolute count) to publish behind the next vmcnt(0)
+            unsigned long long pvn = pv;        // upwind progress asked for a block ahead
+
+#define COL_BLOCK(JM)                                                                                              \
+            {                                                                                                      \
+                /* ---- boundary j: chunk j - 2 is behind every lane, chunk j + 1 is wanted in 15 steps */         \
+                if (j >= 2 && CS * (j - 2) < wend && (imp1 || imp2))                                               \
+                    col_writeback<(JM + 1) % 3>(lp, cuni_ptr(tcol + zlo(j - 2)), wbg, wbl);                        \
+                if ((j & 1) && j >= 3) pub_pending = k0 + (j - 1) / 2;      /* tile (j - 3) / 2 is complete */     \
+                if ((j & 1) && !closed) {                                                                          \
+                    /* the first lane enters tile k0 + tr + 1 in 16 steps: is it part of the run? */              \
+                    const int kt = k0 + (j + 1) / 2;                                                               \
+                    if (kt >= P.NK) closed = true;                                                                 \
+                    else {                                                                                         \
+                        if (known_up <= kt) {                                                                      \
+                            col_upwind(pvn, upvalid, e, P.NK, known_up, upmask);                                   \
+                            if (known_up <= kt) {                                                                  \
+                                if (!col_poll(P, pa, upvalid, col_key(e, kt + 1), pv, s, deadline)) { alive = false; closed = true; } \
+                                else col_upwind(pv, upvalid, e, P.NK, known_up, upmask);                           \
+                            }                                                                                      \
+                            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");                                     \
+                        }                                                                                          \
+                        if (alive && ((((mask0 | upmask | pend) >> kt) & 1u) || imp1)) wend += TILE_Z;             \
+                        else closed = true;                                                                        \
+                    }                                                                                              \
+                }                                                                                                  \
+                if (CS * (j + 1) <= wend)                                                                          \
+                    col_stage<(JM + 1) % 3>(lp, cuni_ptr(vcol + zlo(j + 1)), cuni_ptr(tcol + zlo(j + 1)), goff, lane); \
+                if (upvalid) pvn = cld64(pa);                                                                      \
+                const int tb = CS * j - wlo;                                                                       \
+                const unsigned span = (unsigned)max(whi() - wlo, 0);                                               \
+                unsigned long long imp = 0;                                                                        \
+                ColSteps<CS * JM, CS - 2>::run(lp, AX, r, cc, tb, span, imp);                                      \
+                /* (the block's last two steps read the next chunk: a lane's next cell but one, its neighbours' next) */ \
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                   \
+                if (pub_pending >= 0) {                                                                            \
+                    if (lane == 0) __hip_atomic_store(prog + col, ((unsigned long long)col_key(e, pub_pending) << 32) \
+                                                      | mymask | (tilebits << k0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); \
+                    published = pub_pending;                                                                       \
+                    pub_pending = -1;                                                                              \
+                }                                                                                                  \
+                ColSteps<CS * JM + CS - 2, 2>::run(lp, AX, r, cc, tb, span, imp);                                  \
+                imp2 = imp1;                                                                                       \
+                imp1 = imp != 0ull;                                                                                \
+                if (imp1) {                                                                                        \
+                    tilebits |= 1u << (j >> 1);                                                                    \
+                    if (j >= 1) tilebits |= 1u << ((j - 1) >> 1);                                                  \
+                    if (closed) late = true;                                                                       \
+                }                                                                                                  \
+                j++;                                                                                               \
+            }
+
+            int j = 0;
+            for (;;) {
+                if (CS * j >= wend + CSIG + 1) break;
+                COL_BLOCK(0)
+                if (CS * j >= wend + CSIG + 1) break;
+                COL_BLOCK(1)
+                if (CS * j >= wend + CSIG + 1) break;
+                COL_BLOCK(2)
+            }
+#undef COL_BLOCK
+            // ---- the last chunk(s) of the run: blocks 0 .. j - 1 ran, chunks up to j - 3 are written back
+            const int nt = wend / TILE_Z;                       // tiles of the run
+            tilebits &= nt >= 32 ? ~0u : ((1u << nt) - 1u);
+            if (imp1 || imp2) {
+                // (chunk j - 2 = 2 nt - 1, the run's last one; j = 2 nt + 1: its slot is (j - 2) mod 3)
+                float *const dst = cuni_ptr(tcol + zlo(j - 2));
+                const int slot = (j - 2) % 3;
+                if (slot == 0) col_writeback<0>(lp, dst, wbg, wbl);
+                else if (slot == 1) col_writeback<1>(lp, dst, wbg, wbl);
+                else col_writeback<2>(lp, dst, wbg, wbl);
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            mymask |= tilebits << k0;
+            const int kend = k0 + nt;
+            if (late && kend < P.NK) pend |= 1u << kend;
+            if (lane == 0) __hip_atomic_store(prog + col, ((unsigned long long)col_key(e, kend) << 32) | mymask,
+                                              __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            published = kend;
+            {   // work: the cells of the run's tiles that lie inside the grid
+                unsigned long long cells = 0;
+                for (int t = k0; t < kend; t++) {
+                    const int K = sz > 0 ? t : P.NK - 1 - t;
+                    cells += (unsigned long long)(dx * dy * min(TILE_Z, L.n[2] - K * TILE_Z));
+                }
+                col_work_add(P, work, s, cells, (unsigned)nt, lane);
+            }
+            k = kend;
+            if (!alive) break;
+        }
+        if (!alive) continue;
+
+        // ---- seal: the column is done with sweep e
+        if (published < P.NK && lane == 0)
+            __hip_atomic_store(prog + col, ((unsigned long long)col_key(e, P.NK) << 32) | mymask, __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT);
+        if (mymask != 0u) {
+            // whoever comes EARLIER in this sweep's order and touches an improved tile has to look again: the
+            // tile itself (other orderings), the tile below it in sweep order, the two upwind columns
+            const unsigned own = mymask | (mymask >> 1);
+            const unsigned own_abs = sz > 0 ? own : col_flip(own, P.NK), my_abs = sz > 0 ? mymask : col_flip(mymask, P.NK);
+            unsigned *const due = P.due + (size_t)s * ncol;
+            if (lane == 0) atomicOr(due + col, own_abs);
+            if (upvalid) atomicOr(due + ncolumn, my_abs);
+            if (lane == 0) P.changed[s] = CHANGED_IMPROVED;
+        }
+        unsigned long long old = 0;
+        if (lane == 0) old = atomicAdd(P.seal + (size_t)s * COL_MAX_SWEEPS + e, 1ull | ((unsigned long long)(mymask != 0u) << 32));
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (lane == 0) {
+            __hip_atomic_store(prog + col, ((unsigned long long)col_key(e, 0xff) << 32) | mymask, __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT);
+            if ((unsigned)old + 1u == (unsigned)ncol && (old >> 32) + (unsigned long long)(mymask != 0u) == 0ull) {
+                // the last column of sweep e, and no tile of the start improved in it: the start is at rest
+                __hip_atomic_store(P.done + s, e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (atomicSub(P.status + 1, 1u) == 1u) atomicCAS(P.status, (unsigned)COL_RUNNING, (unsigned)COL_DONE);
+            }
+        }
+    }
+    col_work_flush(P, work);
+}
+
+// ---------------------------------------------------------------------------
+// first state of a solve: every column sealed in "sweep 0", the start's tile (and its neighbours) due
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+column_init_kernel(ColumnSolve P, const StartDesc *__restrict__ starts, int from_box)
+{
+    const int ncol = P.NI * P.NJ;
+    const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (t < (long long)P.nstart * ncol) {
+        const int s = (int)(t / ncol), col = (int)(t - (long long)s * ncol);
+        const int I = col / P.NJ, J = col - I * P.NJ;
+        const StartDesc &sd = starts[s];
+        const int si = sd.sa / TILE_X, sj = sd.sb / TILE_Y, sk = sd.sc / TILE_Z;
+        unsigned m = 0;
+        if (from_box) m = P.NK >= 32 ? ~0u : ((1u << P.NK) - 1u);
+        else if (abs(I - si) <= 1 && abs(J - sj) <= 1)
+            for (int K = max(sk - 1, 0); K <= min(sk + 1, P.NK - 1); K++) m |= 1u << K;
+        P.due[t] = m;
+        P.prog[t] = (unsigned long long)col_key(0, 0xff) << 32;
+    }
+    if (t < (long long)P.nstart * COL_MAX_SWEEPS) P.seal[t] = 0ull;
+    if (t < P.nstart) { P.done[t] = 0; P.changed[t] = 0; }
+    if (t < COL_SEQS * 16) P.claim[t] = 0ull;
+    if (t == 0) { P.status[0] = COL_RUNNING; P.status[1] = (unsigned)P.nstart; }
+}
+
+hipError_t column_solve_wgs_per_cu(int *wgs)
+{
+    static bool raised = false;
+    if (!raised) {
+        const hipError_t e = hipFuncSetAttribute((const void *)column_solve_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, CLDSB);
+        if (e != hipSuccess) return e;
+        raised = true;
+    }
+    int n = 0;
+    const hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, (const void *)column_solve_kernel, 64, CLDSB);
+    if (e != hipSuccess) return e;
+    *wgs = std::min(std::max(n, 1), (int)COL_WAVES);
+    return hipSuccess;
+}
+
+hipError_t launch_column_init(const ColumnSolve &P, const StartDesc *starts, bool from_box, hipStream_t st)
+{
+    const long long n = std::max<long long>(std::max<long long>((long long)P.nstart * P.NI * P.NJ, (long long)P.nstart * COL_MAX_SWEEPS),
+                                            COL_SEQS * 16);
+    hipLaunchKernelGGL(column_init_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, P, starts, from_box ? 1 : 0);
+    return hipGetLastError();
+}
+
+hipError_t launch_column_solve(const ColumnSolve &P, int nblocks, hipStream_t st)
+{
+    if (P.nstart < 1 || P.NK < 1 || P.NK > COL_MAX_NK || P.nseq < 1 || P.nseq > COL_SEQS || nblocks < P.nseq
+        || P.L.lo[0] != 1 || P.L.lo[1] != 1 || P.L.lo[2] < CS || P.L.lo[2] % CS || P.L.s1 % CS
+        || P.L.p[2] - P.L.lo[2] - P.NK * TILE_Z < CS)
+        return hipErrorInvalidValue;
+    hipLaunchKernelGGL(column_solve_kernel, dim3((unsigned)nblocks), dim3(64), CLDSB, st, P);
+    return hipGetLastError();
+}
+
+} // namespace ttsweep

@@ -125,6 +125,15 @@ struct ttsweep_ctx {
     unsigned long long *d_tile_wgwork = nullptr;    // private work sums of the sweep kernel's workgroups
     size_t tile_wgwork_cap = 0;
     int *d_tile_dmin = nullptr, *h_tile_dmin = nullptr;    // first hyperplane with a due tile, per sweep parity (device / pinned)
+    // TILE, plain 6-neighbour star, one launch per solve (ColumnSolve, ttsweep_dev.h)
+    ttsweep::ColumnSolve col{};
+    unsigned long long *d_col_prog = nullptr, *d_col_seal = nullptr, *d_col_claim = nullptr;
+    unsigned *d_col_due = nullptr, *d_col_status = nullptr, *h_col_status = nullptr;   // (h_: pinned)
+    int *d_col_done = nullptr, *h_col_done = nullptr, *d_col_seqtab = nullptr;
+    int col_cap_starts = 0;                 // starts the buffers above were sized for
+    int col_seq_key[3] = {0, 0, 0};         // NI, NJ, sequences the table on the device was made for
+    int col_blocks = 0;                     // single-wavefront workgroups the device holds at once
+    int tile_blocks_used = 0;               // workgroups whose private work sums the solve in progress has to add up
     int *d_tile_flags = nullptr;            // capacity_starts x activity words (flag_words)
     unsigned long long *d_work = nullptr;   // capacity_starts
     unsigned long long *h_work = nullptr;   // pinned

@@ -272,4 +272,42 @@ struct TileSweep {
     TileEntry ent[TILE_MAX_ENT];
 };
 
+// ---------------------------------------------------------------------------
+// TILE, plain 6-neighbour star, one launch per solve: column pipelines (ttsweep_column.hip)
+// ---------------------------------------------------------------------------
+// A COLUMN is the stack of NK tiles above one tile position (I, J).  One wavefront owns a column for one
+// ordering sweep and relaxes its due tiles as ONE systolic pipeline along z (lane (i', j') is i' + j' cells
+// behind the first lane; the pipeline does not drain between consecutive due tiles), through a ring of
+// three 16-cell chunks per image row in LDS.  Columns are claimed in the order of the sweep (by tile level
+// I' + J', per XCD sequence) and wait for each other through one 64-bit progress word per column and
+// start: sweep (24 bits) | tiles finished, 0xff = sealed (8) | tiles improved in this sweep (32, in sweep
+// order).  Which tiles are due in a LATER sweep is kept in one word of bits per column (absolute K).
+constexpr int COL_MAX_NK = 32;              // tiles of a column (bits of a mask word)
+constexpr int COL_MAX_SWEEPS = 4096;        // per-start, per-sweep seal counters
+constexpr int COL_SEQS = 8;                 // claim sequences (one per XCD)
+constexpr int COL_WAVES = 4;                // wavefronts (columns in flight) per workgroup = per CU
+enum : unsigned { COL_RUNNING = 0, COL_DONE = 1, COL_ERR_TIMEOUT = 2, COL_ERR_CAP = 3 };
+
+struct ColumnSolve {
+    DevLayout L;
+    const float *v;
+    float *T0;                      // padded travel-time volume of start 0; start s: + s * L.cells
+    int nstart;
+    int NI, NJ, NK;
+    int nseq;                       // claim sequences in use (<= COL_SEQS)
+    int seq_off[COL_SEQS], seq_len[COL_SEQS];
+    const int *seqtab;              // sequence x: positions I' | J' << 16 in sweep order, from seq_off[x] on
+    unsigned long long *prog;       // [nstart][NI * NJ] progress words
+    unsigned *due;                  // [nstart][NI * NJ] due bits
+    unsigned long long *seal;       // [nstart][COL_MAX_SWEEPS]: columns sealed | columns that improved << 32
+    int *done;                      // [nstart]: the sweep after which the start was at rest (0: running)
+    unsigned long long *claim;      // [COL_SEQS][16]: next entry of each sequence (128 bytes apart)
+    unsigned *status;               // [0]: COL_RUNNING / COL_DONE / error; [1]: starts still running
+    unsigned long long *wgwork;     // [waves][nstart][2]: private work sums (relaxations, tiles)
+    int *changed;                   // per start: CHANGED_IMPROVED when anything improved
+    float h[6];                     // d / 2 of the entries x-, y-, z-, z+, y+, x+
+    int max_sweeps;
+    long long timeout_ticks;        // wall-clock ticks (100 MHz) after which every wait gives up
+};
+
 } // namespace ttsweep

@@ -189,6 +189,10 @@ static bool use_async(ttsweep_ctx *ctx, int nstart)
     // (planners take up to ASYNC_MAX_RINGS workgroups of the resident grid: a device that holds only a handful
     // keeps the pass driver)
     if (ensure_unit_grid(ctx) || ctx->unitq_blocks < 4 * ASYNC_MAX_RINGS) return false;
+    // (a ring serves at most ASYNC_RING_STARTS starts, and there are as many rings as XCDs: a device or a partition
+    // with fewer XCDs holds fewer starts per launch - the pass driver takes what does not fit)
+    const int nrings = std::max(std::min(std::min(nstart, ctx->nlists), (int)ASYNC_MAX_RINGS), 1);
+    if ((nstart + nrings - 1) / nrings > ASYNC_RING_STARTS) return false;
     return true;        // (-1: wherever it can run; 1: the same)
 }
 
@@ -335,6 +339,139 @@ static int solve_async_strip(ttsweep_ctx *ctx, int nstart, std::vector<int> &swe
     return any ? 1 : 0;
 }
 
+
+// TILE, plain 6-neighbour star: can the solve run as ONE launch of column pipelines (ColumnSolve, ttsweep_dev.h)?
+static bool use_column(ttsweep_ctx *ctx, int nstart)
+{
+    if (ctx->kernel != TTSWEEP_KERNEL_TILE || ctx->async_mode == 0) return false;
+    if (!tile_star_is_six(ctx->tile_ent, ctx->tile_nent, ctx->tile_R)) return false;
+    const DevLayout &L = ctx->L;
+    const int NI = tile_count(L.n[0], TILE_X), NJ = tile_count(L.n[1], TILE_Y), NK = tile_count(L.n[2], TILE_Z);
+    if (NK > COL_MAX_NK || NI > 32767 || NJ > 32767 || nstart > 32767) return false;
+    // (the staging instructions address a column's rows with 32-bit byte offsets)
+    if ((9 * L.s0 + 9 * L.s1) * 4 + 64 >= 0x7fffffffLL) return false;
+    if (ctx->col_blocks == 0) {
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, ctx->device) != hipSuccess) return false;
+        int per_cu = 0;
+        if (column_solve_wgs_per_cu(&per_cu) != hipSuccess) return false;
+        ctx->col_blocks = per_cu * std::max(prop.multiProcessorCount, 1);
+    }
+    return ctx->col_blocks >= COL_SEQS;
+}
+
+// The whole driver loop as one launch: claim sequences, first state, the launch, its verdict.  sweeps[s]: ordering
+// sweeps start s took part in.  Returns 1 / 0 (something improved / nothing did), -2 (a wait inside the launch ran
+// into its wall-clock limit: the boxes hold valid upper bounds, the caller goes on with the hyperplane launches) or < 0.
+static int solve_column(ttsweep_ctx *ctx, int nstart, bool from_box, std::vector<int> &sweeps)
+{
+    const DevLayout &L = ctx->L;
+    ColumnSolve &C = ctx->col;
+    C = ColumnSolve{};
+    C.L = L;
+    C.v = ctx->d_v;
+    C.T0 = ctx->d_T;
+    C.nstart = nstart;
+    C.NI = tile_count(L.n[0], TILE_X);
+    C.NJ = tile_count(L.n[1], TILE_Y);
+    C.NK = tile_count(L.n[2], TILE_Z);
+    const int ncol = C.NI * C.NJ;
+    C.nseq = std::min((int)COL_SEQS, C.NI);
+    if (ctx->nlists >= 1 && ctx->nlists < C.nseq) C.nseq = ctx->nlists;
+    // sequence x: the positions (I', J') with I' % nseq == x in the order of the sweep: by level I' + J', then by I'
+    std::vector<int> tab;
+    tab.reserve(ncol);
+    for (int x = 0; x < C.nseq; x++) {
+        C.seq_off[x] = (int)tab.size();
+        for (int lev = 0; lev <= C.NI + C.NJ - 2; lev++)
+            for (int ip = x; ip < C.NI; ip += C.nseq) {
+                const int jp = lev - ip;
+                if (jp >= 0 && jp < C.NJ) tab.push_back(ip | (jp << 16));
+            }
+        C.seq_len[x] = (int)tab.size() - C.seq_off[x];
+    }
+    if (ctx->col_seq_key[0] != C.NI || ctx->col_seq_key[1] != C.NJ || ctx->col_seq_key[2] != C.nseq || !ctx->d_col_seqtab) {
+        if (ctx->d_col_seqtab) HIPCHK(hipFree(ctx->d_col_seqtab));
+        ctx->d_col_seqtab = nullptr;
+        HIPCHK(hipMalloc((void **)&ctx->d_col_seqtab, tab.size() * sizeof(int)));
+        HIPCHK(hipMemcpy(ctx->d_col_seqtab, tab.data(), tab.size() * sizeof(int), hipMemcpyHostToDevice));
+        ctx->col_seq_key[0] = C.NI; ctx->col_seq_key[1] = C.NJ; ctx->col_seq_key[2] = C.nseq;
+    }
+    if (nstart > ctx->col_cap_starts) {
+        if (ctx->d_col_prog) HIPCHK(hipFree(ctx->d_col_prog));
+        if (ctx->d_col_due) HIPCHK(hipFree(ctx->d_col_due));
+        if (ctx->d_col_seal) HIPCHK(hipFree(ctx->d_col_seal));
+        if (ctx->d_col_done) HIPCHK(hipFree(ctx->d_col_done));
+        if (ctx->h_col_done) HIPCHK(hipHostFree(ctx->h_col_done));
+        ctx->d_col_prog = nullptr; ctx->d_col_due = nullptr; ctx->d_col_seal = nullptr; ctx->d_col_done = nullptr;
+        ctx->h_col_done = nullptr;
+        ctx->col_cap_starts = 0;
+        HIPCHK(hipMalloc((void **)&ctx->d_col_prog, (size_t)nstart * ncol * sizeof(unsigned long long)));
+        HIPCHK(hipMalloc((void **)&ctx->d_col_due, (size_t)nstart * ncol * sizeof(unsigned)));
+        HIPCHK(hipMalloc((void **)&ctx->d_col_seal, (size_t)nstart * COL_MAX_SWEEPS * sizeof(unsigned long long)));
+        HIPCHK(hipMalloc((void **)&ctx->d_col_done, (size_t)nstart * sizeof(int)));
+        HIPCHK(hipHostMalloc((void **)&ctx->h_col_done, (size_t)nstart * sizeof(int)));
+        ctx->col_cap_starts = nstart;
+    }
+    if (!ctx->d_col_claim) HIPCHK(hipMalloc((void **)&ctx->d_col_claim, COL_SEQS * 16 * sizeof(unsigned long long)));
+    if (!ctx->d_col_status) HIPCHK(hipMalloc((void **)&ctx->d_col_status, 8 * sizeof(unsigned)));
+    if (!ctx->h_col_status) HIPCHK(hipHostMalloc((void **)&ctx->h_col_status, 8 * sizeof(unsigned)));
+    // the resident grid: no more workgroups than a sweep has columns (a workgroup that finds nothing to do waits
+    // inside a later sweep), whole rounds of the sequences
+    long long blocks = std::min<long long>(ctx->col_blocks, (long long)ncol * nstart);
+    blocks = std::max<long long>(blocks / C.nseq, 1) * C.nseq;
+    const size_t need = (size_t)blocks * (size_t)nstart * 2;
+    if (need > ctx->tile_wgwork_cap) {
+        if (ctx->d_tile_wgwork) HIPCHK(hipFree(ctx->d_tile_wgwork));
+        ctx->d_tile_wgwork = nullptr;
+        ctx->tile_wgwork_cap = 0;
+        HIPCHK(hipMalloc((void **)&ctx->d_tile_wgwork, need * sizeof(unsigned long long)));
+        ctx->tile_wgwork_cap = need;
+    }
+    HIPCHK(hipMemsetAsync(ctx->d_tile_wgwork, 0, need * sizeof(unsigned long long), ctx->stream));
+    C.seqtab = ctx->d_col_seqtab;
+    C.prog = ctx->d_col_prog;
+    C.due = ctx->d_col_due;
+    C.seal = ctx->d_col_seal;
+    C.done = ctx->d_col_done;
+    C.claim = ctx->d_col_claim;
+    C.status = ctx->d_col_status;
+    C.wgwork = ctx->d_tile_wgwork;
+    C.changed = ctx->d_changed;
+    static const int order[6] = {0, 1, 2, 3, 4, 5};     // (tile_star_is_six: x-, y-, z-, z+, y+, x+)
+    for (int e = 0; e < 6; e++) C.h[e] = ctx->tile_ent[order[e]].h;
+    C.max_sweeps = (int)std::min<long long>(ctx->max_sweeps, COL_MAX_SWEEPS - 2);
+    // every wait inside the launch gives up after this much wall clock (100 MHz ticks): ten seconds plus twenty
+    // times what forty sweep equivalents should take at a quarter of the memory rate
+    const double expect_s = (double)L.n[0] * L.n[1] * L.n[2] * (double)nstart * 12.0 * 40.0 / 2.0e12;
+    C.timeout_ticks = (long long)((10.0 + 20.0 * expect_s) * 1.0e8);
+    if (ctx->async_timeout_ms > 0) C.timeout_ticks = (long long)ctx->async_timeout_ms * 100000ll;
+
+    HIPCHK(launch_column_init(C, ctx->d_starts, from_box, ctx->stream));
+    hipEvent_t e0, e1;
+    if (ctx->timing && timed_event(ctx, &e0)) return -1;
+    HIPCHK(launch_column_solve(C, (int)blocks, ctx->stream));
+    if (ctx->timing && timed_event(ctx, &e1)) return -1;
+    ctx->stats.launches++;
+    HIPCHK(hipMemcpyAsync(ctx->h_col_status, ctx->d_col_status, 8 * sizeof(unsigned), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipMemcpyAsync(ctx->h_col_done, ctx->d_col_done, (size_t)nstart * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipMemcpyAsync(ctx->h_changed, ctx->d_changed, (size_t)nstart * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    if (ctx->h_col_status[0] == COL_ERR_CAP)
+        return set_error("a start did not converge in %lld sweeps", ctx->max_sweeps);
+    if (ctx->h_col_status[0] != COL_DONE) {
+        set_error("the one-launch solve gave up (code %u)", ctx->h_col_status[0]);
+        return -2;
+    }
+    bool any = false;
+    for (int s = 0; s < nstart; s++) {
+        any |= (ctx->h_changed[s] & CHANGED_IMPROVED) != 0;
+        sweeps[s] = ctx->h_col_done[s];
+    }
+    ctx->tile_blocks_used = (int)blocks;
+    return any ? 1 : 0;
+}
+
 int solve_device_body(ttsweep_ctx *ctx, int nstart, const ttsweep_start *starts,
                              float *const *tt_dev, int init)
 {
@@ -350,6 +487,7 @@ int solve_device_body(ttsweep_ctx *ctx, int nstart, const ttsweep_start *starts,
     const int np = pairs ? STRIP_PLANES : 1;
     if (np != ctx->np) ctx->unit_order_key.assign(ctx->unit_order_key.size(), -1);     // orders belong to the other unit grid
     ctx->np = np;
+    const bool column = use_column(ctx, nstart);
 
     for (int s = 0; s < nstart; s++) {
         const int u[3] = {starts[s].i, starts[s].j, starts[s].k};
@@ -375,7 +513,7 @@ int solve_device_body(ttsweep_ctx *ctx, int nstart, const ttsweep_start *starts,
         else HIPCHK(launch_pack(L, tt_dev[s], sd.T, INFINITY, ctx->stream));
         if (ctx->kernel == TTSWEEP_KERNEL_STRIP)
             HIPCHK(launch_init_tile_flags(L, sd, /*from_box=*/!init, ctx->plans[np - 1].ra, np, ctx->stream));
-        if (ctx->kernel == TTSWEEP_KERNEL_TILE) {
+        if (ctx->kernel == TTSWEEP_KERNEL_TILE && !column) {
             HIPCHK(launch_init_tile_state(L, sd, /*from_box=*/!init, ctx->stream));
             float *const faces = ctx->d_tface + (size_t)s * tile_face_cells(L, ctx->tile_fz);
             if (init) HIPCHK(launch_init_tile_faces(L, faces, ctx->tile_fz, sd.sa, sd.sb, sd.sc, ctx->stream));
@@ -410,7 +548,7 @@ int solve_device_body(ttsweep_ctx *ctx, int nstart, const ttsweep_start *starts,
     ctx->pass_index = 0;
     ctx->defer_suspended = false;
     ctx->tile_epoch = 1;
-    if (ctx->kernel == TTSWEEP_KERNEL_TILE && prepare_tile_sweep(ctx)) return -1;
+    if (ctx->kernel == TTSWEEP_KERNEL_TILE && !column && prepare_tile_sweep(ctx)) return -1;
     bool async = use_async(ctx, nstart);
     if (ctx->kernel == TTSWEEP_KERNEL_STRIP && !async) {
         if (build_worklist(ctx, nstart)) return -1;
@@ -438,7 +576,31 @@ int solve_device_body(ttsweep_ctx *ctx, int nstart, const ttsweep_start *starts,
     // what this one recorded, so sweeps are enqueued one at a time; STRIP / CELL: one ahead)
     const int depth = ctx->kernel == TTSWEEP_KERNEL_TILE ? 1 : 2;
     bool anychange_ever = false;
+    bool fell_back = false;     // the one-launch form gave up: the other driver finishes the solve
     auto t_pass = std::chrono::steady_clock::now();
+    ctx->tile_blocks_used = ctx->tile_blocks;
+    if (column) {
+        HIPCHK(hipMemsetAsync(ctx->d_changed, 0, (size_t)nstart * sizeof(int), ctx->stream));
+        const int rc = solve_column(ctx, nstart, /*from_box=*/!init, sweeps);
+        if (rc == -2) {
+            // A wait inside the launch ran into its wall-clock limit.  Every travel time in the boxes is the length
+            // of a real path: the hyperplane launches take over from there, with every tile due.
+            for (int s = 0; s < nstart; s++) {
+                HIPCHK(launch_init_tile_state(L, ctx->h_starts[s], /*from_box=*/true, ctx->stream));
+                HIPCHK(launch_build_tile_faces(L, ctx->h_starts[s].T, ctx->d_tface + (size_t)s * tile_face_cells(L, ctx->tile_fz),
+                                               ctx->tile_fz, ctx->stream));
+                sweeps[s] = 0;
+            }
+            if (prepare_tile_sweep(ctx)) return -1;
+            ctx->tile_blocks_used = ctx->tile_blocks;
+            anychange_ever = true;
+            fell_back = true;
+        } else {
+            if (rc < 0) return rc;
+            anychange_ever = rc > 0;
+            nactive = 0;
+        }
+    }
     if (async) {
         const int rc = solve_async_strip(ctx, nstart, sweeps);
         if (rc == -2) {
@@ -453,6 +615,7 @@ int solve_device_body(ttsweep_ctx *ctx, int nstart, const ttsweep_start *starts,
             for (int s = 0; s < nstart; s++) sweeps[s] = 0;
             anychange_ever = true;
             async = false;
+            fell_back = true;
         } else {
             if (rc < 0) return rc;
             anychange_ever = rc > 0;
@@ -567,7 +730,7 @@ int solve_device_body(ttsweep_ctx *ctx, int nstart, const ttsweep_start *starts,
             HIPCHK(launch_unpack(L, ctx->h_starts[s].T, tt_dev[s], ctx->stream));
     }
     if (ctx->kernel == TTSWEEP_KERNEL_TILE)
-        HIPCHK(launch_tile_reduce_work(ctx->d_tile_wgwork, ctx->tile_blocks, nstart, ctx->d_work, ctx->stream));
+        HIPCHK(launch_tile_reduce_work(ctx->d_tile_wgwork, ctx->tile_blocks_used, nstart, ctx->d_work, ctx->stream));
     HIPCHK(hipMemcpyAsync(ctx->h_work, ctx->d_work, 3 * nstart * sizeof(unsigned long long),
                           hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipEventRecord(ctx->ev_solve1, ctx->stream));
@@ -594,6 +757,10 @@ int solve_device_body(ttsweep_ctx *ctx, int nstart, const ttsweep_start *starts,
         ctx->stats.cells_relaxed += ctx->kernel != TTSWEEP_KERNEL_CELL
             ? (long long)(ctx->h_work[3 * s] / std::max<size_t>(ctx->pull.size(), 1))
             : (long long)sweeps[s] * ctx->stats.cells;
+    }
+    if (fell_back) {
+        ctx->stats.fallbacks++;
+        set_error("%s", "");    // (the solve succeeded: the one-launch form's complaint is not an error of this call)
     }
     return anychange_ever ? 1 : 0;
 }

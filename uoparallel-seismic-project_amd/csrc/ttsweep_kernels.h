@@ -111,6 +111,15 @@ hipError_t launch_tile_reduce_work(unsigned long long *wgwork, int nblocks, int 
 // from_box = false: only the start's tile counts as changed; true: every tile does.
 hipError_t launch_init_tile_state(const DevLayout &L, const StartDesc &sd, bool from_box, hipStream_t st);
 
+// ---- sweep, variant TILE, plain 6-neighbour star: one launch per solve (ttsweep_column.hip) ----
+// is this the plain 6-neighbour star (pull entries x-, y-, z-, z+, y+, x+, every edge live in both directions)?
+bool tile_star_is_six(const TileEntry *ent, int nent, int R);
+// first state: every column sealed in "sweep 0", the tiles around a start due (from_box: every tile)
+hipError_t launch_column_init(const ColumnSolve &P, const StartDesc *starts, bool from_box, hipStream_t st);
+hipError_t column_solve_wgs_per_cu(int *wgs);       // single-wavefront workgroups a CU holds (and the LDS opt-in)
+// the whole solve: `nblocks` resident single-wavefront workgroups claim columns until every start is at rest
+hipError_t launch_column_solve(const ColumnSolve &P, int nblocks, hipStream_t st);
+
 #ifdef TTSWEEP_TILE_PROFILE
 void tile_prof_dump();   // prints and clears the phase counters of tile_sweep_kernel
 #endif

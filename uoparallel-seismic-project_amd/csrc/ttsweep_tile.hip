@@ -818,18 +818,26 @@ size_t tile_lds_bytes(int R)
 
 typedef void (*tile_sweep_fn)(TileSweep);
 
+// the plain 6-neighbour star (entries in the pull star's sorted order), every edge live in both directions
+bool tile_star_is_six(const TileEntry *ent, int nent, int R)
+{
+    static const int six[6][3] = {{-1, 0, 0}, {0, -1, 0}, {0, 0, -1}, {0, 0, 1}, {0, 1, 0}, {1, 0, 0}};
+    bool is_six = nent == 6 && R == 1;
+    for (int e = 0; e < 6 && is_six; e++)
+        is_six = ent[e].flags == (PULL_FWD | PULL_REV) && ent[e].da == six[e][0] && ent[e].db == six[e][1]
+              && ent[e].dc == six[e][2];
+    return is_six;
+}
+
 // The instance that relaxes this star (see tile_sweep_kernel's template parameters).
 static tile_sweep_fn tile_instance(const TileSweep &P)
 {
     bool exact = false;
     for (int e = 0; e < P.nent; e++) exact |= P.ent[e].flags != (PULL_FWD | PULL_REV);
-    // the plain 6-neighbour star (entries in the pull star's sorted order) has its own instance
-    static const int six[6][3] = {{-1, 0, 0}, {0, -1, 0}, {0, 0, -1}, {0, 0, 1}, {0, 1, 0}, {1, 0, 0}};
+    // the plain 6-neighbour star has its own instance
     // (its face offsets are 32-bit byte offsets from one descriptor: a start's faces must stay
     // below 4 GiB - about a 2600^3 grid -, beyond that the general kernel's 64-bit indices serve)
-    bool is_six = P.nent == 6 && P.R == 1 && !exact && tile_face_cells(P.L, 1) * 4 < 0x100000000LL;
-    for (int e = 0; e < 6 && is_six; e++)
-        is_six = P.ent[e].da == six[e][0] && P.ent[e].db == six[e][1] && P.ent[e].dc == six[e][2];
+    const bool is_six = tile_star_is_six(P.ent, P.nent, P.R) && tile_face_cells(P.L, 1) * 4 < 0x100000000LL;
     if (is_six) return tile_six_kernel;
     if (P.nent <= 6) return exact ? tile_sweep_kernel<6, true> : tile_sweep_kernel<6, false>;
     if (P.nent <= 18) return exact ? tile_sweep_kernel<18, true> : tile_sweep_kernel<18, false>;
