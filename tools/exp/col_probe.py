@@ -5,6 +5,8 @@ import sys, os, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch, ttsweep_pkg
 P = ttsweep_pkg.load()
+if os.environ.get("TTSWEEP_LIB"):       # another build of the same sources (e.g. gpurun_exp/colprof.so: -DTTSWEEP_COL_PROFILE)
+    P._lib.use_library(os.environ["TTSWEEP_LIB"])
 shape = tuple(int(x) for x in sys.argv[1].split(","))
 nstart = int(sys.argv[2])
 reps = int(sys.argv[3]) if len(sys.argv) > 3 else 2

@@ -30,6 +30,7 @@
 #include "ttsweep_kernels.h"
 
 #include <algorithm>
+#include <cstdio>
 #include <vector>
 
 namespace ttsweep {
@@ -239,7 +240,39 @@ __device__ __forceinline__ void col_upwind(unsigned long long pv, bool valid, in
     mask = (unsigned)__builtin_amdgcn_readlane((int)m, 1) | (unsigned)__builtin_amdgcn_readlane((int)m, 2);
 }
 
+// -DTTSWEEP_COL_PROFILE: where the wavefronts' time goes (cycles summed over all wavefronts; tuning aid, never a result)
+#ifdef TTSWEEP_COL_PROFILE
+__device__ unsigned long long g_col_prof[16];
+#define CPROF_NOW() col_cycles()
+#define CPROF_ADD(i, x) prof[i] += (unsigned long long)(x)
+__device__ __forceinline__ long long col_cycles()
+{
+    unsigned long long t;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) :: "memory");
+    return (long long)t;
+}
+#else
+#define CPROF_NOW() 0ll
+#define CPROF_ADD(i, x)
+#endif
+
 } // namespace
+
+#ifdef TTSWEEP_COL_PROFILE
+void column_prof_dump()
+{
+    unsigned long long h[16] = {};
+    (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(g_col_prof), sizeof(h));
+    const double tot = (double)std::max<unsigned long long>(h[0], 1);
+    fprintf(stderr, "column prof: share of resident wavefront time: claim+setup %.3f  wait(previous sweep) %.3f  wait(upwind) %.3f  "
+            "run prologue %.3f  run steps %.3f  in-run waits %.3f  run end+seal %.3f | columns %llu (start at rest %llu, quiet %llu)  "
+            "runs %llu  tiles %llu  blocks %llu  cycles per block %.0f  per tile (steps only) %.0f\n",
+            h[1] / tot, h[2] / tot, h[3] / tot, h[4] / tot, h[5] / tot, h[6] / tot, h[7] / tot, h[8], h[9], h[10], h[11], h[12], h[13],
+            (double)h[5] / (double)std::max<unsigned long long>(h[13], 1), (double)h[5] / (double)std::max<unsigned long long>(h[12], 1));
+    unsigned long long z[16] = {};
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_col_prof), z, sizeof(z));
+}
+#endif
 
 __global__ void __launch_bounds__(64)
 column_solve_kernel(const ColumnSolve P)
@@ -279,9 +312,15 @@ column_solve_kernel(const ColumnSolve P)
     int ci = 0, cj = 0, sig = 0;
     ColConst cc{};
     ColWork work;
+#ifdef TTSWEEP_COL_PROFILE
+    unsigned long long prof[16] = {};
+    const long long prof_begin = CPROF_NOW();
+#endif
 
     for (;;) {
         if (cld32(P.status) != COL_RUNNING) break;
+        const long long pt0 = CPROF_NOW();
+        (void)pt0;
         // ---- claim the next column of this sequence
         unsigned long long q = 0;
         if (lane == 0) q = atomicAdd(P.claim + seq * 16, 1ull);
@@ -291,7 +330,8 @@ column_solve_kernel(const ColumnSolve P)
         if (qs >= COL_MAX_SWEEPS - 2) { col_fail(P, COL_ERR_CAP); break; }
         const int e = 1 + (int)qs;                              // sweep, 1-based
         const int pos = rem / P.nstart, s = rem - pos * P.nstart;
-        if (cld32(reinterpret_cast<const unsigned *>(P.done + s)) != 0u) continue;
+        CPROF_ADD(8, 1);
+        if (cld32(reinterpret_cast<const unsigned *>(P.done + s)) != 0u) { CPROF_ADD(9, 1); CPROF_ADD(1, CPROF_NOW() - pt0); continue; }
         const int packed = seqtab[pos];
         const int ip = packed & 0xffff, jp = packed >> 16;
         const int o = (e - 1) & 7;
@@ -330,7 +370,15 @@ column_solve_kernel(const ColumnSolve P)
         const unsigned long long *const pa = prog + ncolumn;
         unsigned long long pv = 0;
         // nobody is still in sweep e - 1 around this column
+        const long long pt1 = CPROF_NOW();
+        (void)pt1;
+        CPROF_ADD(1, pt1 - pt0);
         if (!col_poll(P, pa, valid && lane < 5, col_key(e - 1, 0xff), pv, s, deadline)) continue;
+        long long pt2 = CPROF_NOW();
+        (void)pt2;
+        CPROF_ADD(2, pt2 - pt1);
+        int prof_runs = 0;
+        (void)prof_runs;
         if (e > P.max_sweeps) { col_fail(P, COL_ERR_CAP); break; }
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
         const bool upvalid = valid && (lane == 1 || lane == 2);
@@ -361,9 +409,12 @@ column_solve_kernel(const ColumnSolve P)
                                                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     published = k;
                 }
+                const long long pw0 = CPROF_NOW();
+                (void)pw0;
                 if (!col_poll(P, pa, upvalid, col_key(e, k + 1), pv, s, deadline)) { alive = false; break; }
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
                 col_upwind(pv, upvalid, e, P.NK, known_up, upmask);
+                CPROF_ADD(3, CPROF_NOW() - pw0);
             }
             const unsigned avail = known_up >= 32 ? ~0u : ((1u << known_up) - 1u);
             const unsigned dm = (mask0 | upmask | pend) & avail & ~((1u << k) - 1u);
@@ -382,6 +433,8 @@ column_solve_kernel(const ColumnSolve P)
             // cells of the run that lie inside the grid: wlo <= w < whi
             const int wlo = sz > 0 ? 0 : max(TILE_Z * (P.NK - k0) - L.n[2], 0);
             auto whi = [&]() { return sz > 0 ? min(wend, L.n[2] - TILE_Z * k0) : wend; };
+            const long long pr0 = CPROF_NOW();
+            (void)pr0;
             col_stage<2>(lp, cuni_ptr(vcol + zlo(-1)), cuni_ptr(tcol + zlo(-1)), goff, lane);
             col_stage<0>(lp, cuni_ptr(vcol + zlo(0)), cuni_ptr(tcol + zlo(0)), goff, lane);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -392,6 +445,11 @@ column_solve_kernel(const ColumnSolve P)
             r.va.x = CLDS_F(AX[0]); r.va.y = CLDS_F(AX[0] + CDX - CROWB);
             r.vb.x = CLDS_F(AX[0] + CDX + CROWB); r.vb.y = CLDS_F(AX[0] + 2 * CDX);
 
+            const long long pr1 = CPROF_NOW();
+            (void)pr1;
+            CPROF_ADD(4, pr1 - pr0);
+            unsigned long long prof_inwait = 0;
+            (void)prof_inwait;
             bool imp1 = false, imp2 = false;    // a cell improved in block j - 1 / j - 2
             bool late = false;                  // ... after the run had been closed
             bool closed = false;
@@ -413,8 +471,10 @@ column_solve_kernel(const ColumnSolve P)
                         if (known_up <= kt) {                                                                      \
                             col_upwind(pvn, upvalid, e, P.NK, known_up, upmask);                                   \
                             if (known_up <= kt) {                                                                  \
+                                const long long pq0 = CPROF_NOW();                                                 \
                                 if (!col_poll(P, pa, upvalid, col_key(e, kt + 1), pv, s, deadline)) { alive = false; closed = true; } \
                                 else col_upwind(pv, upvalid, e, P.NK, known_up, upmask);                           \
+                                prof_inwait += (unsigned long long)(CPROF_NOW() - pq0);                            \
                             }                                                                                      \
                             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");                                     \
                         }                                                                                          \
@@ -460,6 +520,14 @@ column_solve_kernel(const ColumnSolve P)
 #undef COL_BLOCK
             // ---- the last chunk(s) of the run: blocks 0 .. j - 1 ran, chunks up to j - 3 are written back
             const int nt = wend / TILE_Z;                       // tiles of the run
+            const long long pr2 = CPROF_NOW();
+            (void)pr2;
+            CPROF_ADD(5, (unsigned long long)(pr2 - pr1) - prof_inwait);
+            CPROF_ADD(6, prof_inwait);
+            CPROF_ADD(11, 1);
+            CPROF_ADD(12, nt);
+            CPROF_ADD(13, j);
+            prof_runs++;
             tilebits &= nt >= 32 ? ~0u : ((1u << nt) - 1u);
             if (imp1 || imp2) {
                 // (chunk j - 2 = 2 nt - 1, the run's last one; j = 2 nt + 1: its slot is (j - 2) mod 3)
@@ -485,9 +553,13 @@ column_solve_kernel(const ColumnSolve P)
                 col_work_add(P, work, s, cells, (unsigned)nt, lane);
             }
             k = kend;
+            CPROF_ADD(7, CPROF_NOW() - pr2);
             if (!alive) break;
         }
         if (!alive) continue;
+        const long long ps0 = CPROF_NOW();
+        (void)ps0;
+        if (prof_runs == 0) CPROF_ADD(10, 1);
 
         // ---- seal: the column is done with sweep e
         if (published < P.NK && lane == 0)
@@ -515,8 +587,14 @@ column_solve_kernel(const ColumnSolve P)
                 if (atomicSub(P.status + 1, 1u) == 1u) atomicCAS(P.status, (unsigned)COL_RUNNING, (unsigned)COL_DONE);
             }
         }
+        CPROF_ADD(7, CPROF_NOW() - ps0);
     }
     col_work_flush(P, work);
+#ifdef TTSWEEP_COL_PROFILE
+    prof[0] = (unsigned long long)(CPROF_NOW() - prof_begin);
+    if (lane == 0)
+        for (int i = 0; i < 14; i++) atomicAdd(&g_col_prof[i], prof[i]);
+#endif
 }
 
 // ---------------------------------------------------------------------------
