@@ -20,8 +20,8 @@
 //   * A tile is relaxed in sweep e when it is DUE: a neighbour that comes later in the sweep order (or the tile
 //     itself) improved in an earlier sweep (bits in ColumnSolve::due), or an upwind neighbour improved in THIS
 //     sweep (the upwind columns' progress words carry the bits; inside the column the pipeline just goes on).
-//     A sweep in which no tile of a start improved leaves no bit: the start is at rest (counted per start and
-//     sweep when columns seal).
+//     A sweep in which no tile of a start improved leaves no bit: the start is at rest (columns are counted per
+//     start and sweep when they seal; the sweep's last column reads the count).
 // Visibility between workgroups (MI355X_MICROARCH.md, "inter-workgroup visibility"): travel times are stored
 // write-through (sc1), the storing wave waits for its stores (vmcnt(0)) before it publishes progress (an sc1
 // store); a wave that has read progress (sc1 loads) invalidates its L1 (buffer_inv sc1) before it stages.
@@ -575,14 +575,24 @@ column_solve_kernel(const ColumnSolve P)
             if (upvalid) atomicOr(due + ncolumn, my_abs);
             if (lane == 0) P.changed[s] = CHANGED_IMPROVED;
         }
-        unsigned long long old = 0;
-        if (lane == 0) old = atomicAdd(P.seal + (size_t)s * COL_MAX_SWEEPS + e, 1ull | ((unsigned long long)(mymask != 0u) << 32));
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if (lane == 0) {
+        // one count per start and sweep of the columns that are done with it, and of those that improved a tile: the
+        // sweep's last column waits until every column has been counted, and rules on the start (nobody else waits)
+        unsigned long long *const tally = P.seal + (size_t)s * COL_MAX_SWEEPS + e;
+        if (lane == 0) atomicAdd(tally, 1ull | ((unsigned long long)(mymask != 0u) << 32));
+        if (mymask != 0u) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // (the bits are set before anybody sees the seal)
+        if (lane == 0)
             __hip_atomic_store(prog + col, ((unsigned long long)col_key(e, 0xff) << 32) | mymask, __ATOMIC_RELAXED,
                                __HIP_MEMORY_SCOPE_AGENT);
-            if ((unsigned)old + 1u == (unsigned)ncol && (old >> 32) + (unsigned long long)(mymask != 0u) == 0ull) {
-                // the last column of sweep e, and no tile of the start improved in it: the start is at rest
+        if (ip == P.NI - 1 && jp == P.NJ - 1) {
+            unsigned long long seen = 0;
+            for (unsigned spin = 0;; spin++) {
+                seen = cld64(tally);
+                if ((unsigned)seen == (unsigned)ncol) break;
+                if ((spin & 3u) == 3u && (cld32(P.status) != COL_RUNNING || col_clock() > deadline)) break;
+                __builtin_amdgcn_s_sleep(4);
+            }
+            if ((unsigned)seen == (unsigned)ncol && (seen >> 32) == 0ull && lane == 0) {
+                // no tile of the start improved in sweep e: the start is at rest
                 __hip_atomic_store(P.done + s, e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 if (atomicSub(P.status + 1, 1u) == 1u) atomicCAS(P.status, (unsigned)COL_RUNNING, (unsigned)COL_DONE);
             }
