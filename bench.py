@@ -254,7 +254,8 @@ def hbm_regime(P, torch, dev, dev_index, traffic, with_cpu, steps=2):
     """six-FS on 1024x1024x512, 14 starts, TILE kernel (ordered 8-ordering Gauss-Seidel tile
     sweeps): the regime where HBM, not the vector ALUs, binds (24 flops per 12 B).  achieved =
     12 B x cells of the tiles relaxed / time of the sweep launches (HIP events on the library's
-    stream around every ordering sweep), per launch = one tile hyperplane."""
+    stream around them).  One launch per solve (column pipelines, ttsweep_column.hip) or, under
+    the hyperplane driver, one launch per tile hyperplane of an ordering sweep."""
     nx, ny, nz = map(int, HBM_REGIME["grid"].split(","))
     cells = nx * ny * nz
     offs = P.inputs.read_triples(P.inputs.star_path(HBM_REGIME["star"]))
@@ -286,8 +287,12 @@ def hbm_regime(P, torch, dev, dev_index, traffic, with_cpu, steps=2):
     out = {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
            "traffic": traffic["bytes_per_launch"] if traffic else None,
            "traffic_source": traffic["source"] if traffic else "not measured in this run",
-           "kernel": "tile_six_kernel (one tile hyperplane of an ordering sweep: plans and relaxes its due tiles)",
+           "kernel": ("column_solve_kernel (ONE launch per solve: the ordering sweeps, their order and the test for rest run "
+                      "on the device)" if launches == 1 else
+                      "tile_six_kernel (one tile hyperplane of an ordering sweep: plans and relaxes its due tiles)"),
            "launches": int(launches), "avg_launch_ms": st["sweep_kernel_ms"] / launches,
+           "frac_over_solve": alg / dt / 1e9 / HBM_PEAK_GBS if dt > 0 else 0.0,
+           "fallbacks": int(st.get("fallbacks", 0)),
            "algorithmic_bytes_per_launch": alg / launches,
            "workload": f"{nx}x{ny}x{nz} synthetic velocity, six-FS (6-neighbour star), {len(starts)} starts "
                        f"(one GPU's share of start-111), converged multi-start solve",
@@ -376,7 +381,7 @@ def main():
     valu_bound = FLOPS_PER_RELAX * npull / BYTES_PER_CELL_SWEEP > BALANCE_FLOPS_PER_BYTE
     tile_star = npull <= 26 and args.kernel in (0, 3)      # (the library's own choice is read back below)
     # kernels of one sweep launch: the first group is counted (one per launch), all are summed
-    patterns = ([["tile_six_kernel", "tile_sweep_kernel"], ["tile_plan_kernel"]] if tile_star
+    patterns = ([["column_solve_kernel", "tile_six_kernel", "tile_sweep_kernel"], ["tile_plan_kernel"]] if tile_star
                 else [["sweep_units_kernel"], ["plan_pass_kernel"]])
 
     # ---- legs that run other processes on the GPU: before this one initialises it
@@ -386,7 +391,7 @@ def main():
     if world == 1 and not args.no_traffic:
         traffic = measure_traffic(args, patterns)
         if hbm_regime_wanted(args):
-            hbm_traffic = measure_traffic(hbm_regime_args(args), [["tile_six_kernel", "tile_sweep_kernel"], []])
+            hbm_traffic = measure_traffic(hbm_regime_args(args), [["column_solve_kernel", "tile_six_kernel", "tile_sweep_kernel"], []])
     if world == 1 and not args.no_host and small:
         host_e2e = host_program_end_to_end(P, (nx, ny, nz), args.star, starts, v_host)
 
@@ -497,7 +502,8 @@ def main():
         tfl = flops / kern_s / 1e12 if kern_s > 0 else 0.0
         kname = {1: "sweep_cell_kernel", 2: "plan_pass_kernel + sweep_units_kernel (one pass)" if st["launches"] > 1 else
                  "sweep_units_kernel<16, np, true> (ONE launch per solve: ring planners + workers, convergence detected on the device)",
-                 3: "tile_plan_kernel + tile_six_kernel / tile_sweep_kernel (one tile hyperplane of an ordering sweep)"}[st["kernel_variant"]]
+                 3: ("column_solve_kernel (one launch per solve: column pipelines)" if st["launches"] == 1 else
+                     "tile_six_kernel / tile_sweep_kernel (one tile hyperplane of an ordering sweep)")}[st["kernel_variant"]]
         common = {"kernel": kname, "launches": int(launches), "avg_launch_ms": st["sweep_kernel_ms"] / launches,
                   "algorithmic_bytes_per_launch": alg_bytes / launches,
                   "algorithmic_flops_per_launch": flops / launches,
@@ -527,7 +533,8 @@ def main():
                        "gather": gather,
                        "kernel_variant": st["kernel_variant"],
                        "driver": ("one launch per solve (ring planners + workers, convergence detected on the device)"
-                                  if st["kernel_variant"] == 2 and st["launches"] == 1 else "a launch (pair) per pass / hyperplane, convergence tested on the host"),
+                                  if st["kernel_variant"] in (2, 3) and st["launches"] == 1 else "a launch (pair) per pass / hyperplane, convergence tested on the host"),
+                       "fallbacks": int(st.get("fallbacks", 0)),
                        "library": os.path.relpath(P._lib.LIB_PATH, ROOT),
                        "passes_per_start_mean": sweeps_all / args.steps / nstart,
                        "full_sweep_equivalents_per_start_mean": relaxed_all / cells / args.steps / nstart},

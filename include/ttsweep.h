@@ -100,7 +100,8 @@ typedef struct ttsweep_ctx ttsweep_ctx;
                                          (there: N = fsindex[3], the entries no longer than 4 cells,
                                          146 of the 818).  0 (default) switches it off. */
 
-#define TTSWEEP_OPT_ASYNC          9   /* schedule only, never the result: 1 = the STRIP kernel runs a solve as ONE
+#define TTSWEEP_OPT_ASYNC          9   /* schedule only, never the result: 1 = the STRIP kernel - and the TILE kernel for
+                                          the plain 6-neighbour star (column pipelines) - runs a solve as ONE
                                          launch (no passes: planner workgroups hand the due units, nearest to
                                          their start first, to the working workgroups through rings in device
                                          memory, and detect convergence on the device); 0 = a launch pair per
@@ -133,6 +134,11 @@ typedef struct ttsweep_ctx ttsweep_ctx;
                                          runs into it the launch drains and the pass driver finishes the solve from
                                          the boxes as they stand (same result).  0 (default): ten seconds plus
                                          twenty times the solve's expected duration */
+
+#define TTSWEEP_OPT_TILE_IN_PLACE 19 /* schedule only, never the result (TILE kernel, one launch per solve): 1 (default) =
+                                         relax the travel times in the caller's own device arrays when their rows are
+                                         whole tiles long (nz % 32 == 0) and 64-byte aligned - no padded copy, no copy
+                                         back; 0 = always in the library's padded volumes */
 
 #define TTSWEEP_KERNEL_AUTO       0
 #define TTSWEEP_KERNEL_CELL       1   /* one thread per cell, star from global memory */

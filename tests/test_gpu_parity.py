@@ -485,6 +485,66 @@ def test_tile_kernel_resumes_from_a_damaged_box(P, oracle, shape, seed):
             assert_bit_equal(a, b, f"{name} {shape} start {start} after damage")
 
 
+TILE_DRIVERS = [pytest.param({}, id="columns-in-place"), pytest.param({"OPT_TILE_IN_PLACE": 0}, id="columns-padded"),
+                pytest.param({"OPT_ASYNC": 0}, id="hyperplane-launches")]
+
+
+@pytest.mark.parametrize("options", TILE_DRIVERS)
+@pytest.mark.parametrize("shape,seed", [((20, 37, 96), 51), ((9, 8, 64), 52), ((8, 8, 32), 53), ((33, 70, 19), 54),
+                                        ((17, 16, 97), 55), ((40, 24, 160), 56), ((3, 2, 32), 57)])
+def test_tile_six_star_drivers_vs_oracle(P, oracle, shape, seed, options):
+    """The plain 6-neighbour star under the TILE kernel's three drivers - column pipelines in ONE launch, relaxing
+    in the caller's own arrays (rows of whole tiles: nz % 32 == 0) or in the library's padded volumes, and one launch
+    per tile hyperplane - on ragged grids (partial tiles along x and y, rows of one to five tiles): fresh boxes
+    initialised on the device, boxes that arrive with values (host boxes), a damaged converged box, and the
+    converged boxes solved again; all bit for bit the CPU oracle's fixed point."""
+    import torch
+    rng = np.random.default_rng(seed)
+    v = rng.uniform(0.1, 0.5, size=shape).astype(np.float32)
+    six = P.inputs.read_triples(P.inputs.star_path("six"))
+    fs = P.inputs.make_fs(six)
+    nstart = int(rng.integers(1, 4))
+    starts = np.stack([rng.integers(0, n, size=nstart) for n in shape], axis=1).astype(np.int32)
+    want = [oracle.converge(v, oracle.make_star(six), st, order=1)[0] for st in starts]
+    dev = torch.device("cuda:0")
+    with P.TravelTimeSolver(shape, fs) as sol:
+        sol.set_option(P.OPT_KERNEL, 3)
+        for key, val in options.items():
+            sol.set_option(getattr(P, key), val)
+        sol.set_velocity(v)
+        # fresh boxes, initialised on the device
+        tt = torch.empty((nstart,) + shape, dtype=torch.float32, device=dev)
+        assert sol.solve_device(starts, tt, init=True) == 1
+        st = sol.stats()
+        assert st["kernel_variant"] == 3 and st["fallbacks"] == 0
+        assert (st["launches"] == 1) == ("OPT_ASYNC" not in options)
+        for s in range(nstart):
+            assert_bit_equal(tt[s].cpu().numpy(), want[s], f"{shape} start {starts[s]} (device boxes)")
+        # the converged boxes again: nothing to do
+        assert sol.solve_device(starts, tt, init=False) == 0
+        for s in range(nstart):
+            assert_bit_equal(tt[s].cpu().numpy(), want[s], f"{shape} start {starts[s]} (second solve)")
+        # a damaged box: a block back at INFINITY, a slab raised
+        dmg = tt.clone()
+        lo = [int(rng.integers(0, n)) for n in shape]
+        dmg[:, lo[0]:lo[0] + 9, lo[1]:lo[1] + 5, lo[2]:lo[2] + 40] = float("inf")
+        dmg[:, : max(shape[0] // 2, 1), :, : shape[2] // 2] *= 1.5
+        for s in range(nstart):
+            dmg[s][tuple(starts[s])] = 0
+        assert sol.solve_device(starts, dmg, init=False) == 1
+        for s in range(nstart):
+            assert_bit_equal(dmg[s].cpu().numpy(), want[s], f"{shape} start {starts[s]} (after damage)")
+        # host boxes (staged by the library, solved as boxes that arrive with values)
+        boxes = []
+        for st_ in starts:
+            b = np.full(shape, np.inf, dtype=np.float32)
+            b[tuple(st_)] = 0
+            boxes.append(b)
+        assert sol.solve(starts, boxes) == 1
+        for s in range(nstart):
+            assert_bit_equal(boxes[s], want[s], f"{shape} start {starts[s]} (host boxes)")
+
+
 def test_tile_kernel_512_grid_matches_cell_kernel(P):
     """The HBM-bound regime at size: 6-neighbour star on 512x512x256, two starts.  TILE
     (ordered sweeps) and CELL (one hop per pass, an independent implementation) agree bit for

@@ -1,5 +1,5 @@
 """Experiment: the TILE kernel's two drivers on the plain 6-neighbour star - column pipelines in ONE launch
-(TTSWEEP_OPT_ASYNC = -1 / 1) against one launch per tile hyperplane (0): same boxes bit for bit, time, work.
+(TTSWEEP_OPT_ASYNC = -1 / 1; mode 2: with TTSWEEP_OPT_TILE_IN_PLACE = 0) against one launch per tile hyperplane (0): same boxes bit for bit, time, work.
 python tools/exp/col_probe.py nx,ny,nz nstart [reps] [modes e.g. 1,0]"""
 import sys, os, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
@@ -19,7 +19,9 @@ cells = shape[0] * shape[1] * shape[2]
 digest = {}
 for mode in modes:
     with P.TravelTimeSolver(shape, fs) as sol:
-        sol.set_option(P.OPT_ASYNC, mode)
+        sol.set_option(P.OPT_ASYNC, 1 if mode == 2 else mode)     # (mode 2: columns, in the library's padded volumes)
+        if mode == 2:
+            sol.set_option(P.OPT_TILE_IN_PLACE, 0)
         sol.set_option(P.OPT_TIMING, 1)
         sol.set_velocity(v)
         tt = torch.empty((nstart,) + shape, dtype=torch.float32, device=dev)

@@ -199,6 +199,8 @@ void ttsweep_destroy(ttsweep_ctx *ctx)
     (void)hipFree(ctx->d_col_status);
     (void)hipFree(ctx->d_col_done);
     (void)hipFree(ctx->d_col_seqtab);
+    (void)hipFree(ctx->d_col_tptr);
+    if (ctx->h_col_tptr) (void)hipHostFree(ctx->h_col_tptr);
     if (ctx->h_col_status) (void)hipHostFree(ctx->h_col_status);
     if (ctx->h_col_done) (void)hipHostFree(ctx->h_col_done);
     (void)hipFree(ctx->d_tile_dmin);
@@ -297,6 +299,7 @@ int ttsweep_set_option(ttsweep_ctx *ctx, int key, long long value)
         if (value < 0) return set_error("window must be >= 0");
         ctx->async_window = (float)((double)value / 1000.0);
         return 0;
+    case TTSWEEP_OPT_TILE_IN_PLACE: ctx->col_in_place_off = value == 0; return 0;
     case TTSWEEP_OPT_ASYNC_SPECIAL:
         if (value < 1) return set_error("dead-edge interval must be positive");
         ctx->async_special_every = (int)std::min<long long>(value, 1 << 30);

@@ -40,6 +40,7 @@ namespace {
 typedef __amdgpu_buffer_rsrc_t col_rsrc;
 typedef float col_f2 __attribute__((ext_vector_type(2)));
 typedef unsigned col_u4 __attribute__((ext_vector_type(4)));
+typedef float col_f4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) char *lds_char;
 
 constexpr int CS = 16;                          // cells of a chunk along z
@@ -156,32 +157,74 @@ struct ColSteps<N0, 0> {
                                                const unsigned, unsigned long long &) {}
 };
 
-// chunk (v and T) -> ring slot SLOT: 7 LDS-DMA wave instructions per array, 64 float4 each (the last one 8)
-template <int SLOT>
-__device__ __forceinline__ void col_stage(const lds_char lp, const float *vsrc, const float *tsrc, const unsigned (&goff)[CNDMA],
-                                          const int lane)
+// chunk (v and T) -> ring slot SLOT: 7 LDS-DMA wave instructions per array, 64 float4 each (the last one 8).
+// tvalid: bit q set - this lane's row of instruction q exists in the travel-time volume (the caller's array has
+// no rows around the grid: those image rows hold +INFINITY, col_fill_rows); zin: the chunk lies inside the rows
+// (a chunk in front of z = 0 or behind the last cell is +INFINITY in the image instead).
+// RIM: the column lies at the rim of the grid or the chunk outside the rows (the caller's array only): the general
+// form; everywhere else both arrays are staged without a test.
+template <int SLOT, bool RIM>
+__device__ __forceinline__ void col_stage(const lds_char lp, const float *vsrc, const float *tsrc, const unsigned (&goffv)[CNDMA],
+                                          const unsigned (&gofft)[CNDMA], const int lane, const unsigned tvalid, const bool zin)
 {
     const col_rsrc rv = col_make_rsrc(vsrc), rt = col_make_rsrc(tsrc);
 #pragma unroll
     for (int q = 0; q < CNDMA; q++) {
         if (q < CNDMA - 1 || lane < (CNR * (CS / 4)) % 64) {
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rv, (__attribute__((address_space(3))) void *)(lp + SLOT * CSLOTB + q * 1024),
-                                                     16, (int)goff[q], 0, 0, 0);
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rt, (__attribute__((address_space(3))) void *)(lp + CARRB + SLOT * CSLOTB + q * 1024),
-                                                     16, (int)goff[q], 0, 0, 0);
+                                                     16, (int)goffv[q], 0, 0, 0);
+            if (!RIM || zin) {
+                if (!RIM || ((tvalid >> q) & 1u))
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rt, (__attribute__((address_space(3))) void *)(lp + CARRB + SLOT * CSLOTB + q * 1024),
+                                                             16, (int)gofft[q], 0, 0, 0);
+            } else {
+                const float inf = __builtin_inff();
+                *reinterpret_cast<__attribute__((address_space(3))) col_f4 *>(lp + CARRB + SLOT * CSLOTB + q * 1024 + lane * 16) =
+                    col_f4{inf, inf, inf, inf};
+            }
         }
     }
+}
+template <int SLOT>
+__device__ __forceinline__ void col_stage_any(const lds_char lp, const float *vsrc, const float *tsrc, const unsigned (&goffv)[CNDMA],
+                                              const unsigned (&gofft)[CNDMA], const int lane, const unsigned tvalid, const bool zin,
+                                              const bool rim)
+{
+    if (rim || !zin) col_stage<SLOT, true>(lp, vsrc, tsrc, goffv, gofft, lane, tvalid, zin);
+    else col_stage<SLOT, false>(lp, vsrc, tsrc, goffv, gofft, lane, tvalid, zin);
+}
+
+// the image rows that do not exist in the travel-time volume (tvalid) hold +INFINITY in every ring slot
+__device__ __forceinline__ void col_fill_rows(const lds_char lp, const int lane, const unsigned tvalid)
+{
+    const float inf = __builtin_inff();
+#pragma unroll
+    for (int slot = 0; slot < CRING; slot++)
+#pragma unroll
+        for (int q = 0; q < CNDMA; q++)
+            if ((q < CNDMA - 1 || lane < (CNR * (CS / 4)) % 64) && !((tvalid >> q) & 1u))
+                *reinterpret_cast<__attribute__((address_space(3))) col_f4 *>(lp + CARRB + slot * CSLOTB + q * 1024 + lane * 16) =
+                    col_f4{inf, inf, inf, inf};
 }
 
 // the 64 interior rows of the T chunk in ring slot SLOT -> the volume (write-through: sc1)
 template <int SLOT>
-__device__ __forceinline__ void col_writeback(const lds_char lp, float *tdst, const unsigned (&wbg)[4], const int (&wbl)[4])
+__device__ __forceinline__ void col_writeback(const lds_char lp, float *tdst, const unsigned (&wbg)[4], const int (&wbl)[4],
+                                              const unsigned wbvalid, const bool rim)
 {
     const col_rsrc rt = col_make_rsrc(tdst);
+    if (rim) {
 #pragma unroll
-    for (int k = 0; k < 4; k++) {
-        const col_u4 x = *reinterpret_cast<__attribute__((address_space(3))) const col_u4 *>(lp + wbl[k] + SLOT * CSLOTB);
-        __builtin_amdgcn_raw_buffer_store_b128(x, rt, (int)wbg[k], 0, 16 /* sc1 */);
+        for (int k = 0; k < 4; k++) {
+            const col_u4 x = *reinterpret_cast<__attribute__((address_space(3))) const col_u4 *>(lp + wbl[k] + SLOT * CSLOTB);
+            if ((wbvalid >> k) & 1u) __builtin_amdgcn_raw_buffer_store_b128(x, rt, (int)wbg[k], 0, 16 /* sc1 */);
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const col_u4 x = *reinterpret_cast<__attribute__((address_space(3))) const col_u4 *>(lp + wbl[k] + SLOT * CSLOTB);
+            __builtin_amdgcn_raw_buffer_store_b128(x, rt, (int)wbg[k], 0, 16 /* sc1 */);
+        }
     }
 }
 
@@ -286,19 +329,20 @@ column_solve_kernel(const ColumnSolve P)
     const int ncol = P.NI * P.NJ;
 
     // per-lane constants of the staging and write-back instructions (image coordinates: the same for every ordering)
-    unsigned goff[CNDMA];
+    unsigned goffv[CNDMA], gofft[CNDMA];
 #pragma unroll
     for (int q = 0; q < CNDMA; q++) {
         const int sidx = 64 * q + lane, r = sidx >> 2, quad = sidx & 3;
         const int ri = (r + 1) / (TILE_Y + 2), rj = (r + 1) % (TILE_Y + 2);        // padded image coordinates 0 .. 9
-        goff[q] = (unsigned)(((long long)ri * L.s0 + (long long)rj * L.s1) * 4 + quad * 16);
+        goffv[q] = (unsigned)(((long long)ri * L.s0 + (long long)rj * L.s1) * 4 + quad * 16);
+        gofft[q] = (unsigned)(((long long)ri * P.ts0 + (long long)rj * P.ts1) * 4 + quad * 16);
     }
     unsigned wbg[4];
     int wbl[4];
 #pragma unroll
     for (int k = 0; k < 4; k++) {
         const int sidx = 64 * k + lane, ir = sidx >> 2, quad = sidx & 3, ci = ir >> 3, cj = ir & 7;
-        wbg[k] = (unsigned)(((long long)(ci + 1) * L.s0 + (long long)(cj + 1) * L.s1) * 4 + quad * 16);
+        wbg[k] = (unsigned)(((long long)(ci + 1) * P.ts0 + (long long)(cj + 1) * P.ts1) * 4 + quad * 16);
         wbl[k] = CARRB + ((ci + 1) * (TILE_Y + 2) + cj) * CROWB + quad * 16;
     }
 
@@ -392,10 +436,31 @@ column_solve_kernel(const ColumnSolve P)
         mask0 = (unsigned)cuni((int)mask0);
         if (sz < 0) mask0 = col_flip(mask0, P.NK);
 
-        const long long colbase = (long long)(I * TILE_X) * L.s0 + (long long)(J * TILE_Y) * L.s1 + L.lo[2];
-        const float *const vcol = P.v + colbase;
-        float *const tcol = P.T0 + (long long)s * L.cells + colbase;
+        const float *const vcol = P.v + (long long)(I * TILE_X) * L.s0 + (long long)(J * TILE_Y) * L.s1 + L.lo[2];
+        // (image row (0, 0) of the column: one row and one column in front of the tile; the caller's array has none
+        // there - the address is then only ever the base of offsets that lead back into the array)
+        float *const tcol = cuni_ptr(P.tptr[s]) + (long long)(I * TILE_X - 1 + P.tpad) * P.ts0
+                          + (long long)(J * TILE_Y - 1 + P.tpad) * P.ts1 + P.tlo;
         const int dx = min(TILE_X, L.n[0] - I * TILE_X), dy = min(TILE_Y, L.n[1] - J * TILE_Y);
+        // rows of the image that do not exist in the caller's array (columns at the rim of the grid)
+        unsigned tvalid = (1u << CNDMA) - 1u, wbvalid = 0xfu;
+        const bool rim = P.tpad == 0 && (I == 0 || J == 0 || I * TILE_X + TILE_X + 1 > L.n[0] || J * TILE_Y + TILE_Y + 1 > L.n[1]);
+        if (rim) {
+            tvalid = 0u;
+#pragma unroll
+            for (int q = 0; q < CNDMA; q++) {
+                const int r = (64 * q + lane) >> 2;
+                const int x = I * TILE_X + (r + 1) / (TILE_Y + 2) - 1, y = J * TILE_Y + (r + 1) % (TILE_Y + 2) - 1;
+                if ((unsigned)x < (unsigned)L.n[0] && (unsigned)y < (unsigned)L.n[1]) tvalid |= 1u << q;
+            }
+            wbvalid = 0u;
+#pragma unroll
+            for (int kk = 0; kk < 4; kk++) {
+                const int ir = (64 * kk + lane) >> 2;
+                if (I * TILE_X + (ir >> 3) < L.n[0] && J * TILE_Y + (ir & 7) < L.n[1]) wbvalid |= 1u << kk;
+            }
+            col_fill_rows(lp, lane, tvalid);
+        }
 
         unsigned mymask = 0, pend = 0;      // improved tiles; tiles made due by a late improvement below them
         int published = 0;
@@ -435,8 +500,10 @@ column_solve_kernel(const ColumnSolve P)
             auto whi = [&]() { return sz > 0 ? min(wend, L.n[2] - TILE_Z * k0) : wend; };
             const long long pr0 = CPROF_NOW();
             (void)pr0;
-            col_stage<2>(lp, cuni_ptr(vcol + zlo(-1)), cuni_ptr(tcol + zlo(-1)), goff, lane);
-            col_stage<0>(lp, cuni_ptr(vcol + zlo(0)), cuni_ptr(tcol + zlo(0)), goff, lane);
+            // (the caller's rows end where the grid ends: a chunk in front of or behind them is not staged)
+            auto zin = [&](int cr) { return P.tpad != 0 || (unsigned)zlo(cr) < (unsigned)L.n[2]; };
+            col_stage_any<2>(lp, cuni_ptr(vcol + zlo(-1)), cuni_ptr(tcol + zlo(-1)), goffv, gofft, lane, tvalid, zin(-1), rim);
+            col_stage_any<0>(lp, cuni_ptr(vcol + zlo(0)), cuni_ptr(tcol + zlo(0)), goffv, gofft, lane, tvalid, zin(0), rim);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             ColRegs r;
             r.vzu = CLDS_F(AX[CPER - 1] + CDX); r.tzu = CLDS_F(AX[CPER - 1] + CARRB + CDX);
@@ -461,7 +528,7 @@ column_solve_kernel(const ColumnSolve P)
             {                                                                                                      \
                 /* ---- boundary j: chunk j - 2 is behind every lane, chunk j + 1 is wanted in 15 steps */         \
                 if (j >= 2 && CS * (j - 2) < wend && (imp1 || imp2))                                               \
-                    col_writeback<(JM + 1) % 3>(lp, cuni_ptr(tcol + zlo(j - 2)), wbg, wbl);                        \
+                    col_writeback<(JM + 1) % 3>(lp, cuni_ptr(tcol + zlo(j - 2)), wbg, wbl, wbvalid, rim);          \
                 if ((j & 1) && j >= 3) pub_pending = k0 + (j - 1) / 2;      /* tile (j - 3) / 2 is complete */     \
                 if ((j & 1) && !closed) {                                                                          \
                     /* the first lane enters tile k0 + tr + 1 in 16 steps: is it part of the run? */              \
@@ -483,7 +550,7 @@ column_solve_kernel(const ColumnSolve P)
                     }                                                                                              \
                 }                                                                                                  \
                 if (CS * (j + 1) <= wend)                                                                          \
-                    col_stage<(JM + 1) % 3>(lp, cuni_ptr(vcol + zlo(j + 1)), cuni_ptr(tcol + zlo(j + 1)), goff, lane); \
+                    col_stage_any<(JM + 1) % 3>(lp, cuni_ptr(vcol + zlo(j + 1)), cuni_ptr(tcol + zlo(j + 1)), goffv, gofft, lane, tvalid, zin(j + 1), rim); \
                 if (upvalid) pvn = cld64(pa);                                                                      \
                 const int tb = CS * j - wlo;                                                                       \
                 const unsigned span = (unsigned)max(whi() - wlo, 0);                                               \
@@ -533,9 +600,9 @@ column_solve_kernel(const ColumnSolve P)
                 // (chunk j - 2 = 2 nt - 1, the run's last one; j = 2 nt + 1: its slot is (j - 2) mod 3)
                 float *const dst = cuni_ptr(tcol + zlo(j - 2));
                 const int slot = (j - 2) % 3;
-                if (slot == 0) col_writeback<0>(lp, dst, wbg, wbl);
-                else if (slot == 1) col_writeback<1>(lp, dst, wbg, wbl);
-                else col_writeback<2>(lp, dst, wbg, wbl);
+                if (slot == 0) col_writeback<0>(lp, dst, wbg, wbl, wbvalid, rim);
+                else if (slot == 1) col_writeback<1>(lp, dst, wbg, wbl, wbvalid, rim);
+                else col_writeback<2>(lp, dst, wbg, wbl, wbvalid, rim);
             }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             mymask |= tilebits << k0;
@@ -660,7 +727,8 @@ hipError_t launch_column_solve(const ColumnSolve &P, int nblocks, hipStream_t st
 {
     if (P.nstart < 1 || P.NK < 1 || P.NK > COL_MAX_NK || P.nseq < 1 || P.nseq > COL_SEQS || nblocks < P.nseq
         || P.L.lo[0] != 1 || P.L.lo[1] != 1 || P.L.lo[2] < CS || P.L.lo[2] % CS || P.L.s1 % CS
-        || P.L.p[2] - P.L.lo[2] - P.NK * TILE_Z < CS)
+        || P.L.p[2] - P.L.lo[2] - P.NK * TILE_Z < CS || !P.tptr || P.ts1 % CS || P.ts0 % CS || P.tlo % CS
+        || (P.tpad != 0 && P.tpad != 1) || (P.tpad == 0 && P.L.n[2] % TILE_Z))
         return hipErrorInvalidValue;
     hipLaunchKernelGGL(column_solve_kernel, dim3((unsigned)nblocks), dim3(64), CLDSB, st, P);
     return hipGetLastError();

@@ -130,6 +130,9 @@ struct ttsweep_ctx {
     unsigned long long *d_col_prog = nullptr, *d_col_seal = nullptr, *d_col_claim = nullptr;
     unsigned *d_col_due = nullptr, *d_col_status = nullptr, *h_col_status = nullptr;   // (h_: pinned)
     int *d_col_done = nullptr, *h_col_done = nullptr, *d_col_seqtab = nullptr;
+    float **d_col_tptr = nullptr, **h_col_tptr = nullptr;  // the starts' travel-time volumes (h_: pinned)
+    int col_cap_tptr = 0;
+    bool col_in_place_off = false;          // TTSWEEP_OPT_TILE_IN_PLACE = 0: always relax in the library's padded volumes
     int col_cap_starts = 0;                 // starts the buffers above were sized for
     int col_seq_key[3] = {0, 0, 0};         // NI, NJ, sequences the table on the device was made for
     int col_blocks = 0;                     // single-wavefront workgroups the device holds at once

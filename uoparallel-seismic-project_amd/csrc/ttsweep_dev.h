@@ -290,8 +290,15 @@ enum : unsigned { COL_RUNNING = 0, COL_DONE = 1, COL_ERR_TIMEOUT = 2, COL_ERR_CA
 
 struct ColumnSolve {
     DevLayout L;
-    const float *v;
-    float *T0;                      // padded travel-time volume of start 0; start s: + s * L.cells
+    const float *v;                 // padded velocity volume (layout L)
+    // The travel times are relaxed where they lie: in the padded volumes of the library (layout L: tpad = 1,
+    // tlo = L.lo[2], strides L.s0 / L.s1) or - when the caller's rows are whole tiles long (nz % 32 == 0) - in the
+    // caller's own FLOATBOX arrays (tpad = 0, tlo = 0, strides ny nz / nz): no copy in, no copy out; rows and
+    // chunks that lie outside the grid are then not staged but set to +INFINITY in the image.
+    float *const *tptr;             // [nstart] travel-time volume of every start
+    long long ts0, ts1;             // its strides (floats) along x and y
+    int tpad;                       // rows / columns in front of the grid
+    int tlo;                        // floats in front of z = 0 in a row
     int nstart;
     int NI, NJ, NK;
     int nseq;                       // claim sequences in use (<= COL_SEQS)

@@ -340,6 +340,17 @@ static int solve_async_strip(ttsweep_ctx *ctx, int nstart, std::vector<int> &swe
 }
 
 
+// the caller's FLOATBOX array as a layout without halo (include/floatbox.h:127-129: x * ny * nz + y * nz + z)
+static DevLayout user_layout(const DevLayout &L)
+{
+    DevLayout U = L;
+    for (int d = 0; d < 3; d++) { U.lo[d] = 0; U.n[d] = U.p[d] = L.un[d]; U.perm[d] = d; }
+    U.s1 = U.p[2];
+    U.s0 = (long long)U.p[1] * U.p[2];
+    U.cells = U.s0 * U.p[0];
+    return U;
+}
+
 // TILE, plain 6-neighbour star: can the solve run as ONE launch of column pipelines (ColumnSolve, ttsweep_dev.h)?
 static bool use_column(ttsweep_ctx *ctx, int nstart)
 {
@@ -363,14 +374,25 @@ static bool use_column(ttsweep_ctx *ctx, int nstart)
 // The whole driver loop as one launch: claim sequences, first state, the launch, its verdict.  sweeps[s]: ordering
 // sweeps start s took part in.  Returns 1 / 0 (something improved / nothing did), -2 (a wait inside the launch ran
 // into its wall-clock limit: the boxes hold valid upper bounds, the caller goes on with the hyperplane launches) or < 0.
-static int solve_column(ttsweep_ctx *ctx, int nstart, bool from_box, std::vector<int> &sweeps)
+// Can the column driver relax the travel times in the caller's own arrays (no padded copy, no copy back)?  Their rows
+// have to be whole tiles long and 64-byte aligned.
+static bool column_in_place(const ttsweep_ctx *ctx, int nstart, float *const *tt_dev)
+{
+    const DevLayout &L = ctx->L;
+    if (ctx->col_in_place_off || L.n[2] % TILE_Z) return false;
+    if ((9ll * L.n[1] * L.n[2] + 9ll * L.n[2]) * 4 + 64 >= 0x7fffffffLL) return false;
+    for (int s = 0; s < nstart; s++)
+        if (!tt_dev[s] || (reinterpret_cast<uintptr_t>(tt_dev[s]) & 63u)) return false;
+    return true;
+}
+
+static int solve_column(ttsweep_ctx *ctx, int nstart, bool from_box, float *const *tt_dev, bool in_place, std::vector<int> &sweeps)
 {
     const DevLayout &L = ctx->L;
     ColumnSolve &C = ctx->col;
     C = ColumnSolve{};
     C.L = L;
     C.v = ctx->d_v;
-    C.T0 = ctx->d_T;
     C.nstart = nstart;
     C.NI = tile_count(L.n[0], TILE_X);
     C.NJ = tile_count(L.n[1], TILE_Y);
@@ -413,6 +435,22 @@ static int solve_column(ttsweep_ctx *ctx, int nstart, bool from_box, std::vector
         HIPCHK(hipHostMalloc((void **)&ctx->h_col_done, (size_t)nstart * sizeof(int)));
         ctx->col_cap_starts = nstart;
     }
+    if (nstart > ctx->col_cap_tptr) {
+        if (ctx->d_col_tptr) HIPCHK(hipFree(ctx->d_col_tptr));
+        if (ctx->h_col_tptr) HIPCHK(hipHostFree(ctx->h_col_tptr));
+        ctx->d_col_tptr = nullptr; ctx->h_col_tptr = nullptr;
+        ctx->col_cap_tptr = 0;
+        HIPCHK(hipMalloc((void **)&ctx->d_col_tptr, (size_t)nstart * sizeof(float *)));
+        HIPCHK(hipHostMalloc((void **)&ctx->h_col_tptr, (size_t)nstart * sizeof(float *)));
+        ctx->col_cap_tptr = nstart;
+    }
+    for (int s = 0; s < nstart; s++) ctx->h_col_tptr[s] = in_place ? tt_dev[s] : ctx->d_T + (size_t)s * L.cells;
+    HIPCHK(hipMemcpyAsync(ctx->d_col_tptr, ctx->h_col_tptr, (size_t)nstart * sizeof(float *), hipMemcpyHostToDevice, ctx->stream));
+    C.tptr = ctx->d_col_tptr;
+    C.ts0 = in_place ? (long long)L.n[1] * L.n[2] : L.s0;
+    C.ts1 = in_place ? (long long)L.n[2] : L.s1;
+    C.tpad = in_place ? 0 : 1;
+    C.tlo = in_place ? 0 : L.lo[2];
     if (!ctx->d_col_claim) HIPCHK(hipMalloc((void **)&ctx->d_col_claim, COL_SEQS * 16 * sizeof(unsigned long long)));
     if (!ctx->d_col_status) HIPCHK(hipMalloc((void **)&ctx->d_col_status, 8 * sizeof(unsigned)));
     if (!ctx->h_col_status) HIPCHK(hipHostMalloc((void **)&ctx->h_col_status, 8 * sizeof(unsigned)));
@@ -488,6 +526,7 @@ int solve_device_body(ttsweep_ctx *ctx, int nstart, const ttsweep_start *starts,
     if (np != ctx->np) ctx->unit_order_key.assign(ctx->unit_order_key.size(), -1);     // orders belong to the other unit grid
     ctx->np = np;
     const bool column = use_column(ctx, nstart);
+    bool in_place = column && column_in_place(ctx, nstart, tt_dev);    // TILE, column driver: the caller's arrays ARE the volumes
 
     for (int s = 0; s < nstart; s++) {
         const int u[3] = {starts[s].i, starts[s].j, starts[s].k};
@@ -509,7 +548,11 @@ int solve_device_body(ttsweep_ctx *ctx, int nstart, const ttsweep_start *starts,
         // (STRIP, fresh boxes: one launch for all starts further down)
         const bool batched = init && ctx->kernel == TTSWEEP_KERNEL_STRIP && L.cells % 4 == 0 && nstart <= 65535;
         if (batched) { ctx->h_active[s] = s; continue; }
-        if (init) HIPCHK(launch_init_tt(L, sd.T, sd.sidx, ctx->stream));
+        if (in_place) {
+            // (a fresh box is initialised where it lies: the reference's state, serial_new/...:139-144)
+            if (init) HIPCHK(launch_init_tt(user_layout(L), tt_dev[s], ((long long)starts[s].i * L.un[1] + starts[s].j) * L.un[2] + starts[s].k,
+                                            ctx->stream));
+        } else if (init) HIPCHK(launch_init_tt(L, sd.T, sd.sidx, ctx->stream));
         else HIPCHK(launch_pack(L, tt_dev[s], sd.T, INFINITY, ctx->stream));
         if (ctx->kernel == TTSWEEP_KERNEL_STRIP)
             HIPCHK(launch_init_tile_flags(L, sd, /*from_box=*/!init, ctx->plans[np - 1].ra, np, ctx->stream));
@@ -581,11 +624,12 @@ int solve_device_body(ttsweep_ctx *ctx, int nstart, const ttsweep_start *starts,
     ctx->tile_blocks_used = ctx->tile_blocks;
     if (column) {
         HIPCHK(hipMemsetAsync(ctx->d_changed, 0, (size_t)nstart * sizeof(int), ctx->stream));
-        const int rc = solve_column(ctx, nstart, /*from_box=*/!init, sweeps);
+        const int rc = solve_column(ctx, nstart, /*from_box=*/!init, tt_dev, in_place, sweeps);
         if (rc == -2) {
             // A wait inside the launch ran into its wall-clock limit.  Every travel time in the boxes is the length
             // of a real path: the hyperplane launches take over from there, with every tile due.
             for (int s = 0; s < nstart; s++) {
+                if (in_place) HIPCHK(launch_pack(L, tt_dev[s], ctx->h_starts[s].T, INFINITY, ctx->stream));
                 HIPCHK(launch_init_tile_state(L, ctx->h_starts[s], /*from_box=*/true, ctx->stream));
                 HIPCHK(launch_build_tile_faces(L, ctx->h_starts[s].T, ctx->d_tface + (size_t)s * tile_face_cells(L, ctx->tile_fz),
                                                ctx->tile_fz, ctx->stream));
@@ -595,6 +639,7 @@ int solve_device_body(ttsweep_ctx *ctx, int nstart, const ttsweep_start *starts,
             ctx->tile_blocks_used = ctx->tile_blocks;
             anychange_ever = true;
             fell_back = true;
+            in_place = false;       // (the boxes go back to the caller's arrays at the end)
         } else {
             if (rc < 0) return rc;
             anychange_ever = rc > 0;
@@ -717,7 +762,9 @@ int solve_device_body(ttsweep_ctx *ctx, int nstart, const ttsweep_start *starts,
         if (build_worklist(ctx, nactive)) return -1;
     }
 
-    if (ctx->kernel == TTSWEEP_KERNEL_STRIP && nstart <= 65535 && nstart > 1) {
+    if (in_place) {
+        // (the travel times were relaxed in the caller's arrays)
+    } else if (ctx->kernel == TTSWEEP_KERNEL_STRIP && nstart <= 65535 && nstart > 1) {
         // (all boxes in one launch; the boxes' addresses go through the pinned copy of the "changed" words,
         // which the driver loop is done with: PASS_SLOTS + 1 ints per start hold a pointer per start)
         float **const hp = reinterpret_cast<float **>(ctx->h_changed);
