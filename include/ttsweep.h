@@ -119,7 +119,7 @@ typedef struct ttsweep_ctx ttsweep_ctx;
                                          reported at once only to the units that are not nearer to the start
                                          than the improved cells by more than this many cells (x 1/1000, may be
                                          negative); the units behind the front hear of it when the start is
-                                         otherwise at rest, once, instead of in every pass.  Default 0;
+                                         otherwise at rest, once, instead of in every pass.  Default 1000 (one cell);
                                          <= -1000000000 switches the deferral off */
 #define TTSWEEP_OPT_ASYNC_WINDOW_MILLI 15 /* schedule only: ring policy 2 - cells (x 1/1000) beyond the nearest unit
                                          with anything to do up to which a start's units are handed out; 0 = no
@@ -206,6 +206,13 @@ int ttsweep_solve_device(ttsweep_ctx *ctx, int nstart, const ttsweep_start *star
                          float *const *tt_dev, int init);
 
 int ttsweep_get_stats(const ttsweep_ctx *ctx, ttsweep_stats *out);
+
+/* Per-start outcome of the last ttsweep_solve / ttsweep_solve_device call of this context: out[s] = 1 when a
+ * travel time of start s improved, 0 when its box was at its fixed point already - what the reference's driver
+ * prints and sums as changed[s] (serial_new/sweep-tt-multistart.c:158-164), where the call's return value is the
+ * OR over the starts.  Writes min(n, starts of that call) entries and returns their number (< 0 on bad
+ * arguments). */
+int ttsweep_get_changed(const ttsweep_ctx *ctx, int *out, int n);
 
 /* On-device fixed-point check in the spirit of testconvergence
  * (old/wavefront-openmp/wave-multistart.c:300-347) on serial_new's edge set:

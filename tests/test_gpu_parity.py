@@ -545,6 +545,51 @@ def test_tile_six_star_drivers_vs_oracle(P, oracle, shape, seed, options):
             assert_bit_equal(boxes[s], want[s], f"{shape} start {starts[s]} (host boxes)")
 
 
+@pytest.mark.parametrize("kernel,star", [(1, "3"), (21, "3"), (23, "3"), (3, "six"), (30, "six")])
+def test_per_start_outcome(P, kernel, star):
+    """ttsweep_get_changed: what the reference's driver prints and sums per start (serial_new/...:158-164) -
+    1 exactly for the boxes a call improved: all of a fresh batch, none of a converged one, and exactly the
+    damaged ones of a batch in which some boxes arrive converged (the call's return value is their OR)."""
+    import torch
+    shape = (40, 33, 64)
+    rng = np.random.default_rng(77)
+    v = rng.uniform(0.1, 0.5, size=shape).astype(np.float32)
+    fs = P.inputs.make_fs(P.inputs.read_triples(P.inputs.star_path(star)))
+    starts = np.array([[3, 4, 5], [20, 20, 40], [39, 0, 63], [10, 30, 1]], np.int32)
+    dev = torch.device("cuda:0")
+    with P.TravelTimeSolver(shape, fs) as sol:
+        if kernel in (21, 23):
+            sol.set_option(P.OPT_KERNEL, 2)
+            sol.set_option(P.OPT_ASYNC, 1 if kernel == 21 else 0)
+        elif kernel == 30:
+            sol.set_option(P.OPT_KERNEL, 3)
+            sol.set_option(P.OPT_ASYNC, 0)
+        else:
+            sol.set_option(P.OPT_KERNEL, kernel)
+        sol.set_velocity(v)
+        tt = torch.empty((4,) + shape, dtype=torch.float32, device=dev)
+        assert sol.solve_device(starts, tt, init=True) == 1
+        assert sol.changed(4) == [1, 1, 1, 1]
+        good = tt.clone()
+        assert sol.solve_device(starts, tt, init=False) == 0
+        assert sol.changed(4) == [0, 0, 0, 0]
+        tt[1, 5:20, 3:9, 10:50] = float("inf")
+        tt[3, :, :, 30:] *= 1.25
+        tt[3][tuple(starts[3])] = 0
+        assert sol.solve_device(starts, tt, init=False) == 1
+        assert sol.changed(4) == [0, 1, 0, 1]
+        assert torch.equal(tt.view(torch.int32), good.view(torch.int32))
+        # host boxes: the same through ttsweep_solve (staged batches), and the confirming call
+        boxes = [good[s].cpu().numpy().copy() for s in range(4)]
+        boxes[2][0:7, :, :] = np.inf
+        boxes[2][tuple(starts[2])] = 0
+        assert sol.solve(starts, boxes) == 1
+        assert sol.changed(4) == [0, 0, 1, 0]
+        assert sol.solve(starts, boxes) == 0
+        assert sol.changed(4) == [0, 0, 0, 0]
+        assert sol.changed(2) == [0, 0]
+
+
 def test_tile_kernel_512_grid_matches_cell_kernel(P):
     """The HBM-bound regime at size: 6-neighbour star on 512x512x256, two starts.  TILE
     (ordered sweeps) and CELL (one hop per pass, an independent implementation) agree bit for

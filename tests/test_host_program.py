@@ -42,6 +42,10 @@ def test_host_program_end_to_end(exe, pkg, oracle, tmp_path):
     assert "starting point 2: 29 3 7" in out
     assert "sweep 1 begin" in out and "sweep 2 finished: anychange = 0" in out
     assert "sweep 3 begin" not in out
+    # per start, as the reference's loop prints it (:158-164; from ttsweep_get_changed): every box moved in the
+    # first pass, none in the confirming one
+    changed = [l for l in out.splitlines() if l.startswith(">>> start")]
+    assert changed == [f">>> start {s}: changed == 1" for s in range(3)] + [f">>> start {s}: changed == 0" for s in range(3)]
 
     lines = (tmp_path / "output.tt").read_text().splitlines()
     assert lines[0] == "30 26 14"

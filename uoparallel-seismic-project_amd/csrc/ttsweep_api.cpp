@@ -413,6 +413,7 @@ int ttsweep_solve_device(ttsweep_ctx *ctx, int nstart, const ttsweep_start *star
     ctx->stats.relaxations_per_sweep = ctx->relax_per_sweep;
     ctx->stats.kernel_variant = ctx->kernel;
     ctx->ev_used = 0;
+    ctx->changed_last.assign(nstart, 0);
     if (nstart == 0) return 0;
     for (int s = 0; s < nstart; s++)        // before anything is queued on the stream
         if (starts[s].i < 0 || starts[s].i >= ctx->nx || starts[s].j < 0 || starts[s].j >= ctx->ny
@@ -436,6 +437,11 @@ int ttsweep_solve_device(ttsweep_ctx *ctx, int nstart, const ttsweep_start *star
     }
     if (ensure_capacity(ctx, nstart)) return -1;
     int rc = solve_device_body(ctx, nstart, starts, tt_dev, init);
+    if (rc >= 0) {
+        for (int s = 0; s < nstart && s < (int)ctx->batch_changed.size(); s++) ctx->changed_last[s] = ctx->batch_changed[s];
+        if (ctx->pre)
+            for (int s = 0; s < nstart && s < (int)ctx->pre->changed_last.size(); s++) ctx->changed_last[s] |= ctx->pre->changed_last[s];
+    }
     if (rc >= 0 && ctx->pre) {
         rc |= pre_rc;
         // (work of the pre-pass in units of the whole star, so that cells_relaxed keeps its meaning)
@@ -533,6 +539,7 @@ int ttsweep_solve(ttsweep_ctx *ctx, int nstart, const ttsweep_start *starts,
             for (int s = 0; s < nstart && known; s++) known = now[s] == ctx->solved[tt_host[s]].digest;
         }
         if (known) {
+            ctx->changed_last.assign(nstart, 0);
             ctx->stats = ttsweep_stats{};
             ctx->stats.nstart = nstart;
             ctx->stats.cells = (long long)cells;
@@ -557,6 +564,7 @@ int ttsweep_solve(ttsweep_ctx *ctx, int nstart, const ttsweep_start *starts,
 
     ttsweep_stats total{};
     int any = 0;
+    std::vector<int> changed_all(nstart, 0);
     for (int first = 0; first < nstart; first += batch) {
         const int n = std::min(batch, nstart - first);
         if ((size_t)n > ctx->stage_cap) {
@@ -662,6 +670,7 @@ int ttsweep_solve(ttsweep_ctx *ctx, int nstart, const ttsweep_start *starts,
         lap("unpin");
         if (rc < 0) return rc;
         any |= rc;
+        for (int s = 0; s < n && s < (int)ctx->changed_last.size(); s++) changed_all[first + s] = ctx->changed_last[s];
         // accumulate the per-batch counters into one report
         const ttsweep_stats &b = ctx->stats;
         total.nstart += b.nstart;
@@ -677,6 +686,7 @@ int ttsweep_solve(ttsweep_ctx *ctx, int nstart, const ttsweep_start *starts,
         total.fallbacks += b.fallbacks;
     }
     ctx->stats = total;
+    ctx->changed_last = changed_all;
     return any;
 }
 
@@ -706,6 +716,14 @@ int ttsweep_validate_device(ttsweep_ctx *ctx, const ttsweep_start *start, const 
     if (cells_infinite) *cells_infinite = (long long)h[1];
     if (cells_unsupported) *cells_unsupported = (long long)h[2];
     return 0;
+}
+
+int ttsweep_get_changed(const ttsweep_ctx *ctx, int *out, int n)
+{
+    if (!ctx || !out || n < 0) return set_error("bad arguments");
+    const int m = std::min(n, (int)ctx->changed_last.size());
+    for (int s = 0; s < m; s++) out[s] = ctx->changed_last[s];
+    return m;
 }
 
 int ttsweep_get_stats(const ttsweep_ctx *ctx, ttsweep_stats *out)

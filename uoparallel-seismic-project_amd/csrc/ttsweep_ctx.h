@@ -177,6 +177,8 @@ struct ttsweep_ctx {
     size_t ev_used = 0;
 
     ttsweep_stats stats{};
+    std::vector<int> batch_changed;         // per start of the device solve in progress: a travel time improved
+    std::vector<int> changed_last;          // ... of the last ttsweep_solve / ttsweep_solve_device call
 };
 
 namespace ttsweep {

@@ -607,6 +607,7 @@ int solve_device_body(ttsweep_ctx *ctx, int nstart, const ttsweep_start *starts,
     // that was launched speculatively for it finds all its units inactive.
     std::vector<int> sweeps(nstart, 0);
     std::vector<char> done(nstart, 0);          // converged: the pass launched one ahead for it is not counted
+    ctx->batch_changed.assign(nstart, 0);
 #ifdef TTSWEEP_DEBUG_ENV
     const bool trace = getenv("TTSWEEP_TRACE") != nullptr;
 #else
@@ -645,6 +646,7 @@ int solve_device_body(ttsweep_ctx *ctx, int nstart, const ttsweep_start *starts,
             anychange_ever = rc > 0;
             nactive = 0;
         }
+        for (int s = 0; s < nstart; s++) ctx->batch_changed[s] |= (ctx->h_changed[s] & CHANGED_IMPROVED) != 0;
     }
     if (async) {
         const int rc = solve_async_strip(ctx, nstart, sweeps);
@@ -666,6 +668,8 @@ int solve_device_body(ttsweep_ctx *ctx, int nstart, const ttsweep_start *starts,
             anychange_ever = rc > 0;
             nactive = 0;
         }
+        // (also when the launch gave up: what it had improved by then stays improved)
+        for (int s = 0; s < nstart; s++) ctx->batch_changed[s] |= (ctx->h_changed[s] & CHANGED_IMPROVED) != 0;
     }
     for (;;) {
     while (processed < launched || nactive > 0) {
@@ -717,7 +721,7 @@ int solve_device_body(ttsweep_ctx *ctx, int nstart, const ttsweep_start *starts,
             if (done[s]) continue;
             sweeps[s]++;
             if (hch[s]) {           // improved, or units still held back by the gate
-                if (hch[s] & CHANGED_IMPROVED) anychange_ever = true;
+                if (hch[s] & CHANGED_IMPROVED) { anychange_ever = true; ctx->batch_changed[s] = 1; }
                 if (sweeps[s] >= ctx->max_sweeps)
                     return set_error("start %d did not converge in %lld sweeps", s, ctx->max_sweeps);
             } else {

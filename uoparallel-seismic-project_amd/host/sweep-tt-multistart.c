@@ -286,8 +286,9 @@ int sweepXYZ(int nx, int ny, int nz, int s, int starstart, int starstop)
                 exit(1);
             }
             ttsweep_get_stats(ctx, &st);
-            /* a start that needed more than its single confirming pass improved */
-            for (n = 0; n < numstart_g; n++) result[n] = rc;
+            /* which boxes moved (:158-164 prints and sums this per start) */
+            if (ttsweep_get_changed(ctx, result, numstart_g) != numstart_g)
+                for (n = 0; n < numstart_g; n++) result[n] = rc;
             if (rc > 0)
                 printf("ttsweep: %d starts, %lld sweeps in total (max %d), %.3f ms on device\n",
                        st.nstart, st.sweeps_total, st.sweeps_max, st.solve_ms);

@@ -154,6 +154,13 @@ class TravelTimeSolver:
         return _check(self._L.ttsweep_solve_device(self._ctx, len(arr), arr, ptrs, int(init)),
                       "ttsweep_solve_device")
 
+    def changed(self, nstart: int):
+        """Per-start outcome of the last solve: 1 where a travel time of that start improved (the
+        reference's changed[s], serial_new/sweep-tt-multistart.c:158-164)."""
+        out = (C.c_int * nstart)()
+        m = _check(self._L.ttsweep_get_changed(self._ctx, out, nstart), "ttsweep_get_changed")
+        return [int(out[s]) for s in range(m)]
+
     def validate_device(self, start, tt):
         """(open_edges, cells_infinite, cells_unsupported) of one box in HBM (torch tensor
         [nx,ny,nz]): the reference's store conditions evaluated on the device, and the cells
