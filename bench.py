@@ -401,12 +401,26 @@ def main():
     dev_index = local_rank % max(ndev, 1)
     dev = torch.device("cuda", dev_index)
     torch.cuda.set_device(dev)
+    ctl = None                  # gloo group for everything that is not the gather: barriers, plans, the max-over-ranks clock
+    rccl_note = None
     if world > 1:
         import torch.distributed as dist
         if args.backend == "nccl":
-            dist.init_process_group("nccl", device_id=dev)
+            # One rank per GPU over RCCL (backend "nccl" IS RCCL on ROCm).  First contact with RCCL must not cost the
+            # line: if the communicator cannot be set up the run goes on under gloo (host gather) and says so.
+            try:
+                dist.init_process_group("nccl", device_id=dev)
+            except Exception as e:      # noqa: BLE001 - whatever RCCL / the rendezvous raises
+                rccl_note = f"init_process_group('nccl') failed: {type(e).__name__}: {e}"[:300]
+                try:
+                    dist.destroy_process_group()
+                except Exception:       # noqa: BLE001
+                    pass
+                args.backend = "gloo"
+                dist.init_process_group("gloo")
         else:
             dist.init_process_group(args.backend)
+        ctl = dist.new_group(backend="gloo") if args.backend == "nccl" else None
 
     if small:
         v_dev = torch.from_numpy(v_host).to(dev)
@@ -447,8 +461,10 @@ def main():
             plan[0] = P.multistart.plan_gather(nstart, cells * 4, free_dev)
             if args.gather != "auto":
                 plan[0] = {"path": args.gather, "bytes": nstart * cells * 4, "why": "--gather"}
-        dist.broadcast_object_list(plan, src=0)
+        dist.broadcast_object_list(plan, src=0, group=ctl)
         gather = plan[0]
+        if rccl_note:
+            gather = dict(gather, path="host", why=rccl_note)
 
     def step():
         sol.solve_device(my_starts, tt, init=True)
@@ -456,9 +472,23 @@ def main():
 
     def fence():
         if dist is not None:
-            dist.barrier()
+            dist.barrier(group=ctl)
         torch.cuda.synchronize()
 
+    if dist is not None and gather["path"] == "device":
+        # the device gather's first run (grouped RCCL send / receive pairs): if it fails on ANY rank, every rank
+        # switches to the host path (agreed over the gloo group) and the line carries the reason
+        err = None
+        try:
+            step()
+            torch.cuda.synchronize()
+        except Exception as e:          # noqa: BLE001
+            err = f"device gather failed on rank {rank}: {type(e).__name__}: {e}"[:300]
+        errs = [None] * world
+        dist.all_gather_object(errs, err, group=ctl)
+        bad = [x for x in errs if x]
+        if bad:
+            gather = dict(gather, path="host", why=bad[0])
     for _ in range(args.warmup):
         step()
     fence()
@@ -477,10 +507,12 @@ def main():
     agg = torch.tensor([dt, float(sweeps_local), float(relaxed_local)], dtype=torch.float64,
                        device=dev if args.backend == "nccl" else "cpu")
     if dist is not None:
+        if ctl is not None:
+            agg = agg.cpu()
         tmax = agg[:1].clone()
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX, group=ctl)
         ssum = agg[1:].clone()
-        dist.all_reduce(ssum, op=dist.ReduceOp.SUM)
+        dist.all_reduce(ssum, op=dist.ReduceOp.SUM, group=ctl)
         dt, sweeps_all, relaxed_all = float(tmax.item()), float(ssum[0].item()), float(ssum[1].item())
     else:
         sweeps_all, relaxed_all = float(sweeps_local), float(relaxed_local)
@@ -547,10 +579,11 @@ def main():
             out["roofline"]["traffic_detail"] = traffic
         if host_e2e:
             out["end_to_end_host_program"] = host_e2e
-        if world == 1 and not args.no_cpu and v_host is not None:
+        if not args.no_cpu and v_host is not None:
+            # (N > 1: serial_new on the box's own host cores in the same run, one core, on rank 0)
             cb = cpu_baseline(P, v_host, offs, starts[0])
             out["cpu_baseline"] = cb
-            ncores = usable_cores()
+            ncores = usable_cores() if world == 1 else 1
             if ncores > 1:
                 multi = cpu_baseline_cores((nx, ny, nz), args.star, args.starts, ncores)
                 if multi is not None:

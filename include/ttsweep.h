@@ -245,6 +245,27 @@ int ttsweep_solve_multi(int ndev, const int *devices, int nx, int ny, int nz,
                         const ttsweep_fs *fs, int starstart, int starstop, const float *v_host,
                         int nstart, const ttsweep_start *starts, float *const *tt_host);
 
+/* The same with the result set RESIDENT ON A DEVICE - the step the reference's MPI version left as a TODO
+ * (mpi/backup.c:381-386: "gather the ttboxes"; its CUDA version moves boxes between devices with peer copies,
+ * cuda/cudasweep-tt-multistart.cu:359-369).  The starts are sharded over `devices` as above; every device
+ * initialises and solves its shard in its own memory (fresh boxes: +INFINITY, 0 at the start), and the converged
+ * boxes are gathered on devices[0], the root: tt_root[s] = device address ON THE ROOT of box s (nx*ny*nz floats,
+ * allocated by the caller: the root holds the whole set - for result sets beyond its memory use ttsweep_solve_multi,
+ * whose boxes live in host memory).  The root's own starts are solved in their slots.  The gather is ONE group of
+ * ncclSend / ncclRecv pairs (RCCL over xGMI: one communicator per listed device, ncclCommInitAll; librccl is
+ * loaded at run time) or - where RCCL is missing, refuses the list (a device listed twice) or fails - peer copies
+ * (hipMemcpyPeerAsync).  flags: TTSWEEP_MULTI_*.  changed (may be NULL): per start, as ttsweep_get_changed.
+ * gather_path (may be NULL): TTSWEEP_GATHER_*.  Returns 1 / 0 / < 0 like ttsweep_solve. */
+#define TTSWEEP_MULTI_LOOPBACK 1    /* testing aid: the root's own boxes travel too (a send to itself) - the collective
+                                       path then runs on a single device */
+#define TTSWEEP_MULTI_NO_RCCL  2    /* peer copies even where RCCL is available */
+#define TTSWEEP_GATHER_NONE 0       /* every box was solved on the root */
+#define TTSWEEP_GATHER_RCCL 1
+#define TTSWEEP_GATHER_PEER 2
+int ttsweep_solve_multi_device(int ndev, const int *devices, int nx, int ny, int nz, const ttsweep_fs *fs, int starstart,
+                               int starstop, const float *v_host, int nstart, const ttsweep_start *starts,
+                               float *const *tt_root, int flags, int *changed, int *gather_path);
+
 /* One-call drop-in for the reference's
  *   int sweepXYZ(int nx,int ny,int nz,int s,int starstart,int starstop)  (:198)
  * with the globals it reads passed explicitly: v = vbox.box.flat,

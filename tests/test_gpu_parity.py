@@ -590,6 +590,72 @@ def test_per_start_outcome(P, kernel, star):
         assert sol.changed(2) == [0, 0]
 
 
+@pytest.mark.parametrize("flags,devices,want_path", [(0, [0], "none"), (1, [0], "rccl-or-peer"), (3, [0], "peer"),
+                                                     (0, [0, 0], "peer"), (1, [0, 0, 0], "peer")])
+def test_solve_multi_device_gathers_on_the_root(P, golden24, flags, devices, want_path):
+    """ttsweep_solve_multi_device (the C host's multi-GPU form with the result set resident on the root device):
+    on the one GPU of this tier the device list is {0} - every box is solved in its slot -, {0} with the loop-back
+    flag - the boxes travel through ONE RCCL group of ncclSend / ncclRecv pairs to the root itself (or through peer
+    copies when RCCL is not to be had) -, and lists that name the device more than once (RCCL refuses them: peer
+    copies).  Always: the golden boxes bit for bit, per-start outcome 1, in the caller's device array."""
+    import torch
+    v = golden24.v
+    fs = P.inputs.make_fs(golden24.star("818"))
+    keys = ["818_mid", "818_corner", "818_deadin", "818_deadout"]
+    starts = np.asarray([golden24.z[f"start_{k}"] for k in keys], np.int32).reshape(-1, 3)
+    want = [golden24.z[f"tt_{k}"] for k in keys]
+    n = len(starts)
+    tt = torch.full((n,) + v.shape, -1.0, dtype=torch.float32, device="cuda:0")
+    rc, changed, path = P.solver.solve_multi_device(devices, v, fs, starts, tt, flags=flags)
+    assert rc == 1 and changed == [1] * n
+    names = {P.solver.GATHER_NONE: "none", P.solver.GATHER_RCCL: "rccl", P.solver.GATHER_PEER: "peer"}
+    assert names[path] in want_path.split("-or-"), (names[path], want_path)
+    for s in range(n):
+        assert_bit_equal(tt[s].cpu().numpy(), want[s], f"start {starts[s]} devices {devices} flags {flags}")
+
+
+def test_rccl_one_rank_group(P, golden24):
+    """First contact with RCCL on the GPU tier: a process group of ONE rank under backend "nccl" (= RCCL on ROCm; all a
+    one-GPU box offers).  multistart.solve_star_split runs its two all-reduces (MAX on the int flag, MIN on the float
+    box) through it, multistart.gather_boxes its grouped send / receive pairs (batch_isend_irecv: the root sends its
+    boxes to itself) - results bit for bit the golden boxes."""
+    import socket
+    import torch
+    import torch.distributed as dist
+    v = golden24.v
+    offs = golden24.star("818")
+    fs = P.inputs.make_fs(offs)
+    keys = ["818_mid", "818_corner"]
+    starts = [golden24.z[f"start_{k}"] for k in keys]
+    sock = socket.socket()
+    sock.bind(("127.0.0.1", 0))
+    port = sock.getsockname()[1]
+    sock.close()
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    assert not dist.is_initialized()
+    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1)
+    try:
+        dev = torch.device("cuda:0")
+        with P.TravelTimeSolver(v.shape, fs) as sol:
+            sol.set_velocity(v)
+            # one start, the star "split" over the one rank: every round ends with the real collectives
+            box = torch.full(v.shape, float("inf"), dtype=torch.float32, device=dev)
+            box[tuple(starts[0])] = 0
+            rounds = P.multistart.solve_star_split(
+                box, lambda b: sol.solve_device([starts[0]], b.unsqueeze(0), init=False) == 1, dist, collectives=True)
+            assert rounds == 2
+            assert_bit_equal(box.cpu().numpy(), golden24.z[f"tt_{keys[0]}"], "star split, one-rank nccl group")
+            # two starts solved here, gathered "to the root" through RCCL send / receive pairs
+            local = torch.empty((2,) + v.shape, dtype=torch.float32, device=dev)
+            assert sol.solve_device(starts, local, init=True) == 1
+            out = P.multistart.gather_boxes(local, 2, dist, path="device", loopback=True)
+            assert out is not None and out.data_ptr() != local.data_ptr()
+            for s, k in enumerate(keys):
+                assert_bit_equal(out[s].cpu().numpy(), golden24.z[f"tt_{k}"], f"gathered {k}")
+    finally:
+        dist.destroy_process_group()
+
+
 def test_tile_kernel_512_grid_matches_cell_kernel(P):
     """The HBM-bound regime at size: 6-neighbour star on 512x512x256, two starts.  TILE
     (ordered sweeps) and CELL (one hop per pass, an independent implementation) agree bit for

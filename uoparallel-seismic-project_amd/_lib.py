@@ -62,6 +62,8 @@ SYMBOLS = [
     ("ttsweep_set_velocity_device", C.c_int, [C.c_void_p, C.c_void_p]),
     ("ttsweep_solve", C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     ("ttsweep_get_changed", C.c_int, [C.c_void_p, C.c_void_p, C.c_int]),
+    ("ttsweep_solve_multi_device", C.c_int, [C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int,
+                                             C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     ("ttsweep_solve_device", C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int]),
     ("ttsweep_get_stats", C.c_int, [C.c_void_p, C.c_void_p]),
     ("ttsweep_validate_device", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,

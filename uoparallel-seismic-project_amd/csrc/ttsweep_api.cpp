@@ -5,6 +5,8 @@
 // There is no CPU fallback in this library: every solve runs HIP kernels or fails.
 #include "ttsweep_ctx.h"
 
+#include <dlfcn.h>
+
 #include <algorithm>
 #include <chrono>
 #include <cmath>
@@ -733,6 +735,199 @@ int ttsweep_get_stats(const ttsweep_ctx *ctx, ttsweep_stats *out)
     return 0;
 }
 
+// Shards balanced by estimated cost (distance from the start to the farthest corner of the grid: the number of
+// passes grows with it), longest first onto the least loaded device, at most ceil(nstart / ndev) starts per device
+// (multistart.all_shards).
+static std::vector<std::vector<int>> cost_balanced_shards(int ndev, int nx, int ny, int nz, int nstart, const ttsweep_start *starts)
+{
+    std::vector<std::vector<int>> shard(ndev);
+    std::vector<double> cost(nstart), load(ndev, 0.0);
+    std::vector<int> order(nstart);
+    const int n[3] = {nx, ny, nz};
+    for (int s = 0; s < nstart; s++) {
+        const int c[3] = {starts[s].i, starts[s].j, starts[s].k};
+        double d2 = 0;
+        for (int a = 0; a < 3; a++) {
+            const double far = std::max(c[a], n[a] - 1 - c[a]);
+            d2 += far * far;
+        }
+        cost[s] = std::sqrt(d2);
+        order[s] = s;
+    }
+    std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return cost[a] > cost[b]; });
+    const size_t cap = (size_t)(nstart + ndev - 1) / ndev;
+    for (int s : order) {
+        int best = -1;
+        for (int d = 0; d < ndev; d++)
+            if (shard[d].size() < cap && (best < 0 || load[d] < load[best])) best = d;
+        shard[best].push_back(s);
+        load[best] += cost[s];
+    }
+    return shard;
+}
+
+// ---- RCCL, loaded at run time (the library does not link it: a host without librccl still has the peer copies) ----
+extern "C++" {
+namespace {
+typedef void *rccl_comm;
+struct Rccl {
+    void *lib = nullptr;
+    int (*CommInitAll)(rccl_comm *, int, const int *) = nullptr;
+    int (*CommDestroy)(rccl_comm) = nullptr;
+    int (*GroupStart)() = nullptr;
+    int (*GroupEnd)() = nullptr;
+    int (*Send)(const void *, size_t, int, int, rccl_comm, hipStream_t) = nullptr;
+    int (*Recv)(void *, size_t, int, int, rccl_comm, hipStream_t) = nullptr;
+    const char *(*GetErrorString)(int) = nullptr;
+    bool ok() const { return CommInitAll && CommDestroy && GroupStart && GroupEnd && Send && Recv; }
+};
+constexpr int RCCL_FLOAT = 7;       // ncclFloat32 (rccl.h: ncclDataType_t)
+
+const Rccl &rccl()
+{
+    static Rccl r = [] {
+        Rccl x;
+        for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+            x.lib = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+            if (x.lib) break;
+        }
+        if (x.lib) {
+            x.CommInitAll = (int (*)(rccl_comm *, int, const int *))dlsym(x.lib, "ncclCommInitAll");
+            x.CommDestroy = (int (*)(rccl_comm))dlsym(x.lib, "ncclCommDestroy");
+            x.GroupStart = (int (*)())dlsym(x.lib, "ncclGroupStart");
+            x.GroupEnd = (int (*)())dlsym(x.lib, "ncclGroupEnd");
+            x.Send = (int (*)(const void *, size_t, int, int, rccl_comm, hipStream_t))dlsym(x.lib, "ncclSend");
+            x.Recv = (int (*)(void *, size_t, int, int, rccl_comm, hipStream_t))dlsym(x.lib, "ncclRecv");
+            x.GetErrorString = (const char *(*)(int))dlsym(x.lib, "ncclGetErrorString");
+        }
+        return x;
+    }();
+    return r;
+}
+} // namespace
+} // extern "C++"
+
+int ttsweep_solve_multi_device(int ndev, const int *devices, int nx, int ny, int nz, const ttsweep_fs *fs, int starstart,
+                               int starstop, const float *v_host, int nstart, const ttsweep_start *starts,
+                               float *const *tt_root, int flags, int *changed, int *gather_path)
+{
+    if (ndev <= 0 || !devices || !starts || !tt_root || !v_host || nstart < 0) return set_error("bad arguments");
+    if (gather_path) *gather_path = TTSWEEP_GATHER_NONE;
+    if (nstart == 0) return 0;
+    const size_t cells = (size_t)nx * ny * nz;
+    const bool loopback = (flags & TTSWEEP_MULTI_LOOPBACK) != 0;
+    const std::vector<std::vector<int>> shard = cost_balanced_shards(ndev, nx, ny, nz, nstart, starts);
+    std::vector<int> rc(ndev, 0);
+    std::vector<std::string> err(ndev);
+    std::vector<float *> local(ndev, nullptr);          // per device: its boxes, one after the other (not the root's,
+                                                        // which are solved where they belong - unless they loop back)
+    std::vector<int> changed_all(nstart, 0);
+    std::vector<std::thread> workers;
+    for (int d = 0; d < ndev; d++) {
+        workers.emplace_back([&, d]() {
+            if (shard[d].empty()) return;
+            const int n = (int)shard[d].size();
+            ttsweep_ctx *ctx = ttsweep_create(devices[d], nx, ny, nz, fs, starstart, starstop);
+            int r = ctx ? ttsweep_set_velocity(ctx, v_host) : -1;
+            std::vector<ttsweep_start> my_starts;
+            std::vector<float *> my_boxes;
+            if (r == 0 && (d != 0 || loopback)) {
+                if (hipSetDevice(devices[d]) != hipSuccess || hipMalloc((void **)&local[d], (size_t)n * cells * sizeof(float)) != hipSuccess) {
+                    set_error("no device memory for %d boxes on device %d", n, devices[d]);
+                    r = -1;
+                }
+            }
+            for (int k = 0; k < n && r == 0; k++) {
+                my_starts.push_back(starts[shard[d][k]]);
+                my_boxes.push_back(local[d] ? local[d] + (size_t)k * cells : tt_root[shard[d][k]]);
+            }
+            if (r == 0) r = ttsweep_solve_device(ctx, n, my_starts.data(), my_boxes.data(), /*init=*/1);
+            if (r >= 0) {
+                std::vector<int> ch(n, 0);
+                (void)ttsweep_get_changed(ctx, ch.data(), n);
+                for (int k = 0; k < n; k++) changed_all[shard[d][k]] = ch[k];
+            }
+            if (r < 0) err[d] = ttsweep_last_error();       // thread-local text
+            ttsweep_destroy(ctx);
+            rc[d] = r;
+        });
+    }
+    for (auto &w : workers) w.join();
+    auto release = [&]() {
+        for (int d = 0; d < ndev; d++)
+            if (local[d]) { (void)hipSetDevice(devices[d]); (void)hipFree(local[d]); }
+    };
+    int any = 0;
+    for (int d = 0; d < ndev; d++) {
+        if (rc[d] < 0) { release(); return set_error("device %d: %s", devices[d], err[d].c_str()); }
+        any |= rc[d];
+    }
+    if (changed) for (int s = 0; s < nstart; s++) changed[s] = changed_all[s];
+
+    // ---- the gather: every box that was solved elsewhere goes into its slot on devices[0]
+    bool anything = false;
+    for (int d = 0; d < ndev; d++) anything |= local[d] != nullptr;
+    if (!anything) return any;
+    std::vector<hipStream_t> streams(ndev, nullptr);
+    auto fail = [&](const char *what, const char *why) {
+        for (int d = 0; d < ndev; d++)
+            if (streams[d]) { (void)hipSetDevice(devices[d]); (void)hipStreamDestroy(streams[d]); }
+        release();
+        return set_error("gather: %s: %s", what, why);
+    };
+    for (int d = 0; d < ndev; d++) {
+        if (hipSetDevice(devices[d]) != hipSuccess || hipStreamCreate(&streams[d]) != hipSuccess)
+            return fail("hipStreamCreate", hipGetErrorString(hipGetLastError()));
+    }
+    bool distinct = true;
+    for (int a = 0; a < ndev; a++)
+        for (int b = a + 1; b < ndev; b++) distinct &= devices[a] != devices[b];
+    bool done = false;
+    if (!(flags & TTSWEEP_MULTI_NO_RCCL) && distinct && rccl().ok()) {
+        // one communicator per listed device, ONE group of send / receive pairs: all inbound xGMI links of the root at once
+        const Rccl &R = rccl();
+        std::vector<rccl_comm> comm(ndev, nullptr);
+        int e = R.CommInitAll(comm.data(), ndev, devices);
+        if (e == 0) {
+            e = R.GroupStart();
+            for (int d = 0; d < ndev && e == 0; d++) {
+                if (!local[d]) continue;
+                for (size_t k = 0; k < shard[d].size() && e == 0; k++) {
+                    e = R.Send(local[d] + k * cells, cells, RCCL_FLOAT, 0, comm[d], streams[d]);
+                    if (e == 0) e = R.Recv(tt_root[shard[d][k]], cells, RCCL_FLOAT, d, comm[0], streams[0]);
+                }
+            }
+            const int e2 = R.GroupEnd();
+            if (e == 0) e = e2;
+            for (int d = 0; d < ndev && e == 0; d++) {
+                (void)hipSetDevice(devices[d]);
+                if (hipStreamSynchronize(streams[d]) != hipSuccess) e = -1;
+            }
+            for (int d = 0; d < ndev; d++)
+                if (comm[d]) (void)R.CommDestroy(comm[d]);
+            done = e == 0;
+        }
+        if (done && gather_path) *gather_path = TTSWEEP_GATHER_RCCL;
+        // (a refused communicator or a failed group: the peer copies below move every box again)
+    }
+    if (!done) {
+        for (int d = 0; d < ndev; d++) {
+            if (!local[d]) continue;
+            (void)hipSetDevice(devices[0]);
+            for (size_t k = 0; k < shard[d].size(); k++)
+                if (hipMemcpyPeerAsync(tt_root[shard[d][k]], devices[0], local[d] + k * cells, devices[d], cells * sizeof(float),
+                                       streams[0]) != hipSuccess)
+                    return fail("hipMemcpyPeerAsync", hipGetErrorString(hipGetLastError()));
+        }
+        (void)hipSetDevice(devices[0]);
+        if (hipStreamSynchronize(streams[0]) != hipSuccess) return fail("hipStreamSynchronize", hipGetErrorString(hipGetLastError()));
+        if (gather_path) *gather_path = TTSWEEP_GATHER_PEER;
+    }
+    for (int d = 0; d < ndev; d++) { (void)hipSetDevice(devices[d]); (void)hipStreamDestroy(streams[d]); }
+    release();
+    return any;
+}
+
 int ttsweep_solve_multi(int ndev, const int *devices, int nx, int ny, int nz,
                         const ttsweep_fs *fs, int starstart, int starstop, const float *v_host,
                         int nstart, const ttsweep_start *starts, float *const *tt_host)
@@ -741,34 +936,7 @@ int ttsweep_solve_multi(int ndev, const int *devices, int nx, int ny, int nz,
     std::vector<int> rc(ndev, 0);
     std::vector<std::string> err(ndev);
     std::vector<std::thread> workers;
-    // Shards balanced by estimated cost (distance from the start to the farthest corner of
-    // the grid: the number of passes grows with it), longest first onto the least loaded
-    // device, at most ceil(nstart / ndev) starts per device (multistart.all_shards).
-    std::vector<std::vector<int>> shard(ndev);
-    {
-        std::vector<double> cost(nstart), load(ndev, 0.0);
-        std::vector<int> order(nstart);
-        const int n[3] = {nx, ny, nz};
-        for (int s = 0; s < nstart; s++) {
-            const int c[3] = {starts[s].i, starts[s].j, starts[s].k};
-            double d2 = 0;
-            for (int a = 0; a < 3; a++) {
-                const double far = std::max(c[a], n[a] - 1 - c[a]);
-                d2 += far * far;
-            }
-            cost[s] = std::sqrt(d2);
-            order[s] = s;
-        }
-        std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return cost[a] > cost[b]; });
-        const size_t cap = (size_t)(nstart + ndev - 1) / ndev;
-        for (int s : order) {
-            int best = -1;
-            for (int d = 0; d < ndev; d++)
-                if (shard[d].size() < cap && (best < 0 || load[d] < load[best])) best = d;
-            shard[best].push_back(s);
-            load[best] += cost[s];
-        }
-    }
+    const std::vector<std::vector<int>> shard = cost_balanced_shards(ndev, nx, ny, nz, nstart, starts);
     for (int d = 0; d < ndev; d++) {
         workers.emplace_back([&, d]() {
             std::vector<ttsweep_start> my_starts;

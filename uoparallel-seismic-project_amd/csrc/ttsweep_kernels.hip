@@ -1249,7 +1249,13 @@ __device__ __forceinline__ void async_planner(const DevLayout &L, const StartDes
 
     for (;;) {
         // ---- wait until the ring has room (and its slots have been read: published - completed
-        // stays well below the capacity)
+        // stays well below the capacity).  `completed` counts finished entries, not a prefix of them: a worker that
+        // has claimed position j and is held up between its claim and its first look at the slot for as long as the
+        // others need for a whole lap of the ring (16 384 units, a millisecond and more of everybody else's work -
+        // only a pre-empted wavefront is) finds the slot published again for j + capacity, waits for a tag that never
+        // comes, and the unit it should have relaxed stays busy: the solve then ends at its wall-clock limit, the pass
+        // driver finishes it from the boxes as they are, and ttsweep_stats.fallbacks says so.  A worker whose claim
+        // lands beyond the tail waits at this ring for the planner's next entries or its done bit (async_claim).
         unsigned h, c;
         for (;;) {
             if (tid == 0) {

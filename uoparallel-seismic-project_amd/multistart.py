@@ -85,7 +85,7 @@ def _same_host(dist) -> bool:
     """Do all ranks run on one machine (one node: the case the north star names)?"""
     import socket
     names = [None] * dist.get_world_size()
-    dist.all_gather_object(names, socket.gethostname())
+    dist.all_gather_object(names, socket.gethostname(), group=_host_group(dist))
     return len(set(names)) == 1
 
 
@@ -103,7 +103,7 @@ def _host_group(dist):
 
 
 def gather_boxes(local, nstart: int, dist=None, dst: int = 0, shards=None, path: str = "device",
-                 shm_dir: str = "/dev/shm", tag: str = "ttsweep"):
+                 shm_dir: str = "/dev/shm", tag: str = "ttsweep", loopback: bool = False):
     """Gather the per-rank stacks of boxes [n_local, nx, ny, nz] on rank `dst`, ordered by
     global start index ([nstart, nx, ny, nz]); other ranks return None.  Ranks may hold
     different numbers of starts (`shards`: the assignment in use, all_shards; round-robin when
@@ -117,10 +117,13 @@ def gather_boxes(local, nstart: int, dist=None, dst: int = 0, shards=None, path:
         one array in shared memory (a file under `shm_dir`), every rank maps it and copies its
         boxes from its GPU straight into their slots (D2H over PCIe, all GPUs at once, no
         inter-process copy); ranks on different machines: the boxes travel as CPU tensors over
-        a gloo group.  The returned tensor is a CPU tensor (shared mapping or plain)."""
+        a gloo group.  The returned tensor is a CPU tensor (shared mapping or plain).
+    loopback (testing aid, path "device"): the root's own boxes travel like everybody else's - a send to
+        itself and the matching receive in the same group -, also in a group of ONE rank: the collective
+        path then runs on a single GPU (a one-rank `nccl` group is the only RCCL a one-GPU box offers)."""
     import torch
 
-    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+    if dist is None or not dist.is_initialized() or (dist.get_world_size() == 1 and not loopback):
         return local
     world, rank = dist.get_world_size(), dist.get_rank()
     if shards is None:
@@ -136,10 +139,13 @@ def gather_boxes(local, nstart: int, dist=None, dst: int = 0, shards=None, path:
         ops = []
         if rank == dst:
             out = torch.empty((nstart,) + box_shape, dtype=local.dtype, device=local.device)
-            for n, s in enumerate(mine):
-                out[s].copy_(local[n])
+            if loopback:
+                ops += [dist.P2POp(dist.isend, local[n], dst) for n in range(len(mine))]
+            else:
+                for n, s in enumerate(mine):
+                    out[s].copy_(local[n])
             for r in range(world):
-                if r != dst:
+                if r != dst or loopback:
                     ops += [dist.P2POp(dist.irecv, out[s], r) for s in shards[r]]
         else:
             ops = [dist.P2POp(dist.isend, local[n], dst) for n in range(len(mine))]
@@ -153,23 +159,30 @@ def gather_boxes(local, nstart: int, dist=None, dst: int = 0, shards=None, path:
     numel = int(np.prod(box_shape)) if box_shape else 1
     if _same_host(dist):
         import os
+        if local.dtype != torch.float32:
+            raise ValueError(f"the shared-memory gather holds float32 boxes, not {local.dtype}")
         name = [None]
         if rank == dst:
             name[0] = os.path.join(shm_dir, f"{tag}_{os.getpid()}_{nstart}x{numel}.f32")
             with open(name[0], "wb") as f:
                 f.truncate(max(nstart * numel, 1) * 4)
-        dist.broadcast_object_list(name, src=dst)
-        out = torch.from_file(name[0], shared=True, size=max(nstart * numel, 1), dtype=torch.float32)
+        ctl = _host_group(dist)                     # (the host path does not depend on RCCL: its hand-shakes run over gloo)
+        try:
+            dist.broadcast_object_list(name, src=dst, group=ctl)
+            out = torch.from_file(name[0], shared=True, size=max(nstart * numel, 1), dtype=torch.float32)
+            dist.barrier(group=ctl)                 # every rank has mapped the file:
+        finally:
+            # ... the name can go - a rank that dies from here on leaves no file (up to 238 GB of host
+            # memory for BASELINE config 5) behind; the mappings keep the pages until they are dropped
+            if rank == dst and name[0] is not None and os.path.exists(name[0]):
+                os.unlink(name[0])
         out = out[: nstart * numel].view((nstart,) + box_shape)
         for n, s in enumerate(mine):
             out[s].copy_(local[n])                  # device -> the shared host array (or host -> host)
         if local.is_cuda:
             torch.cuda.synchronize(local.device)
-        dist.barrier()                              # every slot is written
-        if rank == dst:
-            os.unlink(name[0])                      # (the mapping keeps the memory until it is dropped)
-            return out
-        return None
+        dist.barrier(group=ctl)                     # every slot is written
+        return out if rank == dst else None
     group = _host_group(dist)
     out = None
     ops = []
@@ -222,7 +235,7 @@ def star_slices(noffsets: int, nslice: int):
     return out
 
 
-def solve_star_split(box, slice_solve_fn: Callable, dist=None, max_rounds: int = 100000):
+def solve_star_split(box, slice_solve_fn: Callable, dist=None, max_rounds: int = 100000, collectives: bool = False):
     """One start point on all ranks (precedent: cuda/cudasweep-tt-multistart.cu:316-384, the
     reference's star split with a per-sweep reduction).  Every rank holds the same box
     `box` (torch tensor [nx,ny,nz]: INFINITY, start 0 - or any later state) and relaxes
@@ -238,10 +251,11 @@ def solve_star_split(box, slice_solve_fn: Callable, dist=None, max_rounds: int =
     matter.  This is a correctness path for runs with fewer starts than GPUs, not a fast
     one: shortest paths alternate between offsets of different slices at almost every hop,
     so it needs about as many rounds (each with a reduction of the whole box) as the
-    single-GPU solve needs passes."""
+    single-GPU solve needs passes.  collectives (testing aid): run the two all-reduces also in a
+    group of ONE rank (the only RCCL a one-GPU box offers)."""
     import torch
 
-    multi = dist is not None and dist.is_initialized() and dist.get_world_size() > 1
+    multi = dist is not None and dist.is_initialized() and (dist.get_world_size() > 1 or collectives)
     rounds = 0
     while True:
         rounds += 1

@@ -215,3 +215,36 @@ def sweepXYZ(v: np.ndarray, tt: np.ndarray, fs: np.ndarray, start, starstart: in
                                               fs.ctypes.data, starstart, starstop,
                                               int(start[0]), int(start[1]), int(start[2])),
                   "ttsweep_sweepXYZ")
+
+
+MULTI_LOOPBACK, MULTI_NO_RCCL = 1, 2
+GATHER_NONE, GATHER_RCCL, GATHER_PEER = 0, 1, 2
+
+
+def solve_multi_device(devices, v: np.ndarray, fs: np.ndarray, starts, tt_root, starstart: int = 0,
+                       starstop: int | None = None, flags: int = 0):
+    """ttsweep_solve_multi_device: shard the starts over `devices`, solve in HBM, gather the boxes on
+    devices[0] into tt_root (torch float32 tensor [nstart, nx, ny, nz] on that device).  Returns
+    (rc, changed per start, gather path)."""
+    import torch
+    v = np.ascontiguousarray(v, dtype=np.float32)
+    fs = np.ascontiguousarray(fs, dtype=FS_DTYPE)
+    if starstop is None:
+        starstop = len(fs) - 1
+    arr = TravelTimeSolver._starts_array(starts)
+    n = len(arr)
+    _require(tt_root.is_cuda and tt_root.dtype == torch.float32 and tt_root.is_contiguous()
+             and tuple(tt_root.shape) == (n,) + tuple(v.shape) and tt_root.device.index == devices[0],
+             "tt_root: contiguous float32 [nstart, nx, ny, nz] on devices[0]")
+    ptrs = (C.c_void_p * n)()
+    for s in range(n):
+        ptrs[s] = tt_root.data_ptr() + s * tt_root.stride(0) * 4
+    dev = (C.c_int * len(devices))(*devices)
+    changed = (C.c_int * max(n, 1))()
+    path = C.c_int(0)
+    nx, ny, nz = v.shape
+    torch.cuda.synchronize(tt_root.device)
+    rc = _check(_lib.lib().ttsweep_solve_multi_device(len(devices), dev, nx, ny, nz, fs.ctypes.data, starstart, starstop,
+                                                      v.ctypes.data, n, arr, ptrs, flags, changed, C.byref(path)),
+                "ttsweep_solve_multi_device")
+    return rc, [int(changed[s]) for s in range(n)], path.value
