@@ -93,7 +93,10 @@ __device__ __forceinline__ unsigned col_flip(unsigned m, int nk) { return __brev
 // progress word: sweep << 40 | tiles finished (0xff: sealed) << 32 | improved tiles (sweep order)
 __device__ __forceinline__ unsigned col_key(int sweep, int cnt) { return ((unsigned)sweep << 8) | (unsigned)cnt; }
 
-#define CLDS_F(off) (*reinterpret_cast<__attribute__((address_space(3))) const float *>(lp + (off)))
+// (the kernel has no static LDS: the dynamic array starts at LDS address 0 and an image offset IS the address -
+// checked on the host side of the launch; saves the addition of a base that is zero)
+#define CLDS_F(off) (*reinterpret_cast<__attribute__((address_space(3))) const float *>((unsigned)(off)))
+#define CLDS_W(off) (*reinterpret_cast<__attribute__((address_space(3))) float *>((unsigned)(off)))
 
 // what a lane carries from step to step (lateral neighbours in the pairs the LDS delivers them in: ds_read2_b32)
 struct ColRegs {
@@ -124,17 +127,23 @@ __device__ __forceinline__ void col_step(const lds_char lp, const int (&AX)[CPER
     nva.x = CLDS_F(a1);                         nva.y = CLDS_F(a1 + CDX - CROWB);
     nvb.x = CLDS_F(a1 + CDX + CROWB);           nvb.y = CLDS_F(a1 + 2 * CDX);
     const float vnn = CLDS_F(a2 + CDX), tnn = CLDS_F(a2 + CARRB + CDX);
-    const col_f2 vc2 = {r.vc, r.vc};
-    const col_f2 la = c.ha * (vc2 + r.va), lb = c.hb * (vc2 + r.vb);
+    // (scalar operations, not v_pk_*_f32 over the neighbour pairs: with ONE wavefront on a SIMD the packed forms
+    // issue more slowly than twice the plain ones - measured 123.8 against 126.0 ms per solve on 1024x1024x512 x 14;
+    // the empty asm statements keep the vectoriser from pairing them again)
+    float s0 = r.vc + r.va.x, s1 = r.vc + r.va.y, s2 = r.vc + r.vb.x, s3 = r.vc + r.vb.y;
+    asm volatile("" : "+v"(s0), "+v"(s1), "+v"(s2), "+v"(s3));
+    float l0 = c.ha.x * s0, l1 = c.ha.y * s1, l2 = c.hb.x * s2, l3 = c.hb.y * s3;
+    asm volatile("" : "+v"(l0), "+v"(l1), "+v"(l2), "+v"(l3));
     const float czu = c.hzu * (r.vc + r.vzu) + r.tzu;
     const float czd = c.hzd * (r.vc + r.vn) + r.tn;
     const float pre = fminf(r.tc, fminf(czu, czd));
-    const col_f2 ca = la + ta, cb = lb + tb2;
-    float best = fminf(fminf(pre, fminf(ca.x, ca.y)), fminf(cb.x, cb.y));
+    float c0 = l0 + ta.x, c1 = l1 + ta.y, c2 = l2 + tb2.x, c3 = l3 + tb2.y;
+    asm volatile("" : "+v"(c0), "+v"(c1), "+v"(c2), "+v"(c3));
+    float best = fminf(fminf(pre, fminf(c0, c1)), fminf(c2, c3));
     const bool act = (unsigned)(tb + (N % CS) - c.sigact) < span;      // (tb: the block's first step less the first cell)
     best = act ? best : r.tc;
     imp |= __ballot(best < r.tc);
-    *reinterpret_cast<__attribute__((address_space(3))) float *>(lp + a0 + CARRB + CDX) = best;
+    CLDS_W(a0 + CARRB + CDX) = best;
     r.vzu = r.vc; r.tzu = best;
     r.vc = r.vn; r.tc = r.tn;
     r.vn = vnn; r.tn = tnn;
@@ -326,6 +335,10 @@ column_solve_kernel(const ColumnSolve P)
     const DevLayout &L = P.L;
     const long long clock0 = col_clock();
     const long long deadline = clock0 + P.timeout_ticks;
+    if ((unsigned)(unsigned long long)lp != 0u) {      // (CLDS_F: image offsets are used as LDS addresses)
+        col_fail(P, COL_ERR_LDS_BASE);
+        return;
+    }
     const int ncol = P.NI * P.NJ;
 
     // per-lane constants of the staging and write-back instructions (image coordinates: the same for every ordering)

@@ -286,7 +286,7 @@ constexpr int COL_MAX_NK = 32;              // tiles of a column (bits of a mask
 constexpr int COL_MAX_SWEEPS = 4096;        // per-start, per-sweep seal counters
 constexpr int COL_SEQS = 8;                 // claim sequences (one per XCD)
 constexpr int COL_WAVES = 4;                // wavefronts (columns in flight) per workgroup = per CU
-enum : unsigned { COL_RUNNING = 0, COL_DONE = 1, COL_ERR_TIMEOUT = 2, COL_ERR_CAP = 3 };
+enum : unsigned { COL_RUNNING = 0, COL_DONE = 1, COL_ERR_TIMEOUT = 2, COL_ERR_CAP = 3, COL_ERR_LDS_BASE = 4 };
 
 struct ColumnSolve {
     DevLayout L;
