@@ -1527,6 +1527,9 @@ sweep_units_kernel(DevLayout L, const float *__restrict__ v, const StartDesc *__
     // once - an empty queue then costs no memory round trip, and an empty pass none at all
     int *qcount = head + 2;                         // [0 .. nlists)
     if (!ASYNC && tid < UNITQ_LISTS) qcount[tid] = tid < nlists ? ctrl[tid] : 0;
+#ifdef TTSWEEP_ASYNC_STATS
+    if (tid == 0) head[12] = 0;
+#endif
     __syncthreads();
 
     if (ASYNC) {
@@ -1787,6 +1790,9 @@ sweep_units_kernel(DevLayout L, const float *__restrict__ v, const StartDesc *__
         }
 #pragma unroll
         for (int w = 32; w >= 1; w >>= 1) improved |= __shfl_xor(improved, w);
+#ifdef TTSWEEP_ASYNC_STATS
+        if (ASYNC && improved && lane == 0) atomicOr(&head[12], 1);      // (tuning aid: did this unit improve anything?)
+#endif
         if (ASYNC) {
             // every wave's (write-through) stores have arrived, everybody knows it; then the bits
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1808,6 +1814,14 @@ sweep_units_kernel(DevLayout L, const float *__restrict__ v, const StartDesc *__
             if (tid == 0) {
                 atomicAnd(reinterpret_cast<unsigned *>(tile_flags + 2 * nflag) + my_unit, ~ASYNC_BUSY);
                 atomicAdd(reinterpret_cast<unsigned *>(as.ctl + (size_t)q * ASYNC_CTL_STRIDE + 16), 1u);
+#ifdef TTSWEEP_ASYNC_STATS
+                // units / staged planes relaxed, and those of them that improved no cell (status[4 .. 7])
+                const unsigned np_ = (unsigned)__builtin_popcount(my_planes);
+                atomicAdd(as.status + 4, 1u);
+                atomicAdd(as.status + 5, np_);
+                if (!head[12]) { atomicAdd(as.status + 6, 1u); atomicAdd(as.status + 7, np_); }
+                head[12] = 0;
+#endif
             }
         }
 #ifdef TTSWEEP_PROFILE
