@@ -310,6 +310,38 @@ __device__ __forceinline__ long long col_cycles()
 
 } // namespace
 
+#ifdef TTSWEEP_COL_TRACE
+// -DTTSWEEP_COL_TRACE: a log of the protocol's events (debugging aid): 8 words per record
+__device__ unsigned g_col_trace[8u << 20];
+__device__ unsigned g_col_trace_n;
+#define CTRACE(type, a, b, c, d)                                                                   \
+    if (lane == 0) {                                                                               \
+        const unsigned at = atomicAdd(&g_col_trace_n, 1u);                                         \
+        if (at < (1u << 20)) {                                                                     \
+            unsigned *const w = g_col_trace + 8u * at;                                             \
+            w[0] = (type); w[1] = (unsigned)s; w[2] = (unsigned)e; w[3] = (unsigned)col;           \
+            w[4] = (unsigned)(a); w[5] = (unsigned)(b); w[6] = (unsigned)(c); w[7] = (unsigned)(d); \
+        }                                                                                          \
+    }
+#else
+#define CTRACE(type, a, b, c, d)
+#endif
+
+#ifdef TTSWEEP_COL_TRACE
+void column_trace_dump()
+{
+    unsigned n = 0;
+    (void)hipMemcpyFromSymbol(&n, HIP_SYMBOL(g_col_trace_n), sizeof(n));
+    n = std::min(n, 1u << 20);
+    std::vector<unsigned> h((size_t)n * 8);
+    if (n) (void)hipMemcpyFromSymbol(h.data(), HIP_SYMBOL(g_col_trace), h.size() * 4);
+    const char *path = getenv("TTSWEEP_COL_TRACE_FILE");
+    if (FILE *f = fopen(path ? path : "/tmp/col_trace.bin", "wb")) { fwrite(h.data(), 4, h.size(), f); fclose(f); }
+    const unsigned z = 0;
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_col_trace_n), &z, sizeof(z));
+}
+#endif
+
 #ifdef TTSWEEP_COL_PROFILE
 void column_prof_dump()
 {
@@ -364,10 +396,6 @@ column_solve_kernel(const ColumnSolve P)
     const int *const seqtab = P.seqtab + P.seq_off[seq];
     const long long per = (long long)seqlen * P.nstart;         // entries of one sweep in this sequence
 
-    int cur_o = -1;
-    int AX[CPER];
-    int ci = 0, cj = 0, sig = 0;
-    ColConst cc{};
     ColWork work;
 #ifdef TTSWEEP_COL_PROFILE
     unsigned long long prof[16] = {};
@@ -391,15 +419,19 @@ column_solve_kernel(const ColumnSolve P)
         if (cld32(reinterpret_cast<const unsigned *>(P.done + s)) != 0u) { CPROF_ADD(9, 1); CPROF_ADD(1, CPROF_NOW() - pt0); continue; }
         const int packed = seqtab[pos];
         const int ip = packed & 0xffff, jp = packed >> 16;
-        const int o = (e - 1) & 7;
+        // the eight orderings in Gray-code order: successive sweeps differ in ONE sign, so sweep e + 1 starts at a corner
+        // sweep e passed half-way through (x or y flipped) or at its own first corner (z flipped) and follows it across
+        // the grid; in binary order every second change of sweep flips x and y together - the next sweep then starts
+        // where the previous one ENDS and the two cannot overlap at all
+        const int o = ((e - 1) ^ ((e - 1) >> 1)) & 7;
         const int sx = (o & 1) ? -1 : 1, sy = (o & 2) ? -1 : 1, sz = (o & 4) ? -1 : 1;
         const int I = sx > 0 ? ip : P.NI - 1 - ip, J = sy > 0 ? jp : P.NJ - 1 - jp;
-        if (o != cur_o) {
-            cur_o = o;
-            const int li = lane >> 3, lj = lane & 7;
-            ci = sx > 0 ? li : TILE_X - 1 - li;
-            cj = sy > 0 ? lj : TILE_Y - 1 - lj;
-            sig = li + lj;
+        // the lane's image addresses of the ring period (made anew for every column, new ordering or not: a table that
+        // is carried from column to column and only sometimes rebuilt lives twice in the registers)
+        const int li = lane >> 3, lj = lane & 7;
+        const int ci = sx > 0 ? li : TILE_X - 1 - li, cj = sy > 0 ? lj : TILE_Y - 1 - lj, sig = li + lj;
+        int AX[CPER];
+        {
             const int rxm = ci * (TILE_Y + 2) + cj;             // image row of the x - 1 neighbour (own row: + CDX)
 #pragma unroll
             for (int n = 0; n < CPER; n++) {
@@ -407,11 +439,12 @@ column_solve_kernel(const ColumnSolve P)
                 const int slot = wq >> 4, zc = wq & (CS - 1);
                 AX[n] = slot * CSLOTB + rxm * CROWB + (sz > 0 ? zc : CS - 1 - zc) * 4;
             }
-            cc.ha = col_f2{P.h[0], P.h[1]};
-            cc.hb = col_f2{P.h[4], P.h[5]};
-            cc.hzu = sz > 0 ? P.h[2] : P.h[3];
-            cc.hzd = sz > 0 ? P.h[3] : P.h[2];
         }
+        ColConst cc;
+        cc.ha = col_f2{P.h[0], P.h[1]};
+        cc.hb = col_f2{P.h[4], P.h[5]};
+        cc.hzu = sz > 0 ? P.h[2] : P.h[3];
+        cc.hzd = sz > 0 ? P.h[3] : P.h[2];
         cc.sigact = (I * TILE_X + ci < L.n[0] && J * TILE_Y + cj < L.n[1]) ? sig : 0x3fffffff;
 
         // ---- the progress words of this column (lane 0), its upwind (1, 2) and downwind (3, 4) neighbours
@@ -448,6 +481,7 @@ column_solve_kernel(const ColumnSolve P)
         if (lane == 0) mask0 = atomicExch(P.due + (size_t)s * ncol + col, 0u);
         mask0 = (unsigned)cuni((int)mask0);
         if (sz < 0) mask0 = col_flip(mask0, P.NK);
+        CTRACE(1u, mask0, known_up, upmask, (unsigned)col_clock());
 
         const float *const vcol = P.v + (long long)(I * TILE_X) * L.s0 + (long long)(J * TILE_Y) * L.s1 + L.lo[2];
         // (image row (0, 0) of the column: one row and one column in front of the tile; the caller's array has none
@@ -624,6 +658,7 @@ column_solve_kernel(const ColumnSolve P)
             if (lane == 0) __hip_atomic_store(prog + col, ((unsigned long long)col_key(e, kend) << 32) | mymask,
                                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             published = kend;
+            CTRACE(2u, k0 | (nt << 8) | (kend << 16), tilebits, mask0 | upmask | pend, (unsigned)col_clock());
             {   // work: the cells of the run's tiles that lie inside the grid
                 unsigned long long cells = 0;
                 for (int t = k0; t < kend; t++) {
@@ -659,6 +694,7 @@ column_solve_kernel(const ColumnSolve P)
         // sweep's last column waits until every column has been counted, and rules on the start (nobody else waits)
         unsigned long long *const tally = P.seal + (size_t)s * COL_MAX_SWEEPS + e;
         if (lane == 0) atomicAdd(tally, 1ull | ((unsigned long long)(mymask != 0u) << 32));
+        CTRACE(3u, mymask, o, upmask, (unsigned)col_clock());
         if (mymask != 0u) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // (the bits are set before anybody sees the seal)
         if (lane == 0)
             __hip_atomic_store(prog + col, ((unsigned long long)col_key(e, 0xff) << 32) | mymask, __ATOMIC_RELAXED,
@@ -672,9 +708,11 @@ column_solve_kernel(const ColumnSolve P)
                 __builtin_amdgcn_s_sleep(4);
             }
             if ((unsigned)seen == (unsigned)ncol && (seen >> 32) == 0ull && lane == 0) {
-                // no tile of the start improved in sweep e: the start is at rest
-                __hip_atomic_store(P.done + s, e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (atomicSub(P.status + 1, 1u) == 1u) atomicCAS(P.status, (unsigned)COL_RUNNING, (unsigned)COL_DONE);
+                // no tile of the start improved in sweep e: the start is at rest.  (Sweep e + 1 may be under way behind
+                // sweep e and come to the same end before its last column hears of this one: ONE of them counts.)
+                CTRACE(4u, (unsigned)seen, (unsigned)(seen >> 32), 0, (unsigned)col_clock());
+                if (atomicCAS(P.done + s, 0, e) == 0 && atomicSub(P.status + 1, 1u) == 1u)
+                    atomicCAS(P.status, (unsigned)COL_RUNNING, (unsigned)COL_DONE);
             }
         }
         CPROF_ADD(7, CPROF_NOW() - ps0);

@@ -793,6 +793,9 @@ int solve_device_body(ttsweep_ctx *ctx, int nstart, const ttsweep_start *starts,
 #ifdef TTSWEEP_TILE_PROFILE
     if (ctx->kernel == TTSWEEP_KERNEL_TILE) tile_prof_dump();
 #endif
+#ifdef TTSWEEP_COL_TRACE
+    if (ctx->kernel == TTSWEEP_KERNEL_TILE) column_trace_dump();
+#endif
 #ifdef TTSWEEP_COL_PROFILE
     if (ctx->kernel == TTSWEEP_KERNEL_TILE) column_prof_dump();
 #endif

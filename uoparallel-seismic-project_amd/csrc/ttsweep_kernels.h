@@ -123,6 +123,9 @@ hipError_t launch_column_solve(const ColumnSolve &P, int nblocks, hipStream_t st
 #ifdef TTSWEEP_TILE_PROFILE
 void tile_prof_dump();   // prints and clears the phase counters of tile_sweep_kernel
 #endif
+#ifdef TTSWEEP_COL_TRACE
+void column_trace_dump(); // writes the event log of column_solve_kernel to $TTSWEEP_COL_TRACE_FILE and clears it
+#endif
 #ifdef TTSWEEP_COL_PROFILE
 void column_prof_dump(); // prints and clears the phase counters of column_solve_kernel
 #endif
