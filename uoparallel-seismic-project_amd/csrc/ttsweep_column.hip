@@ -102,13 +102,13 @@ __device__ __forceinline__ unsigned col_key(int sweep, int cnt) { return ((unsig
 struct ColRegs {
     float vc, tc;               // the cell of this step
     float vn, tn;               // the next cell of the row (z-downwind neighbour)
-    float vzu, tzu;             // the previous cell: its velocity, its result (z-upwind neighbour)
+    float wz, tzu;              // the previous cell (z-upwind neighbour): the edge to it (hz (v + v')), its result
     col_f2 va, vb;              // velocities of the lateral neighbours of this step: (x-, y-), (y+, x+)
 };
 
 struct ColConst {
     col_f2 ha, hb;              // d / 2 of (x-, y-), (y+, x+)
-    float hzu, hzd;             // ... of the z-upwind and the z-downwind entry
+    float hz;                   // ... of the two z entries (equal: column_solve's caller checks)
     int sigact;                 // the lane's skew i' + j', or a huge number when its cell column lies outside the grid
 };
 
@@ -134,8 +134,10 @@ __device__ __forceinline__ void col_step(const lds_char lp, const int (&AX)[CPER
     asm volatile("" : "+v"(s0), "+v"(s1), "+v"(s2), "+v"(s3));
     float l0 = c.ha.x * s0, l1 = c.ha.y * s1, l2 = c.hb.x * s2, l3 = c.hb.y * s3;
     asm volatile("" : "+v"(l0), "+v"(l1), "+v"(l2), "+v"(l3));
-    const float czu = c.hzu * (r.vc + r.vzu) + r.tzu;
-    const float czd = c.hzd * (r.vc + r.vn) + r.tn;
+    // (the edge to the next cell is the next step's edge to the previous one: the same sum, the same product)
+    const float wzd = c.hz * (r.vc + r.vn);
+    const float czu = r.wz + r.tzu;
+    const float czd = wzd + r.tn;
     const float pre = fminf(r.tc, fminf(czu, czd));
     float c0 = l0 + ta.x, c1 = l1 + ta.y, c2 = l2 + tb2.x, c3 = l3 + tb2.y;
     asm volatile("" : "+v"(c0), "+v"(c1), "+v"(c2), "+v"(c3));
@@ -144,7 +146,7 @@ __device__ __forceinline__ void col_step(const lds_char lp, const int (&AX)[CPER
     best = act ? best : r.tc;
     imp |= __ballot(best < r.tc);
     CLDS_W(a0 + CARRB + CDX) = best;
-    r.vzu = r.vc; r.tzu = best;
+    r.wz = wzd; r.tzu = best;
     r.vc = r.vn; r.tc = r.tn;
     r.vn = vnn; r.tn = tnn;
     r.va = nva; r.vb = nvb;
@@ -216,24 +218,26 @@ __device__ __forceinline__ void col_fill_rows(const lds_char lp, const int lane,
                     col_f4{inf, inf, inf, inf};
 }
 
-// the 64 interior rows of the T chunk in ring slot SLOT -> the volume (write-through: sc1)
+// the 64 interior rows of the T chunk in ring slot SLOT -> registers (as soon as the last lane has left the chunk:
+// two steps before the block ends) -> the volume (at the block boundary; write-through: sc1)
 template <int SLOT>
-__device__ __forceinline__ void col_writeback(const lds_char lp, float *tdst, const unsigned (&wbg)[4], const int (&wbl)[4],
-                                              const unsigned wbvalid, const bool rim)
+__device__ __forceinline__ void col_wb_read(const lds_char lp, const int (&wbl)[4], col_u4 (&x)[4])
+{
+#pragma unroll
+    for (int k = 0; k < 4; k++)
+        x[k] = *reinterpret_cast<__attribute__((address_space(3))) const col_u4 *>(lp + wbl[k] + SLOT * CSLOTB);
+}
+__device__ __forceinline__ void col_wb_store(float *tdst, const unsigned (&wbg)[4], const col_u4 (&x)[4], const unsigned wbvalid,
+                                             const bool rim)
 {
     const col_rsrc rt = col_make_rsrc(tdst);
     if (rim) {
 #pragma unroll
-        for (int k = 0; k < 4; k++) {
-            const col_u4 x = *reinterpret_cast<__attribute__((address_space(3))) const col_u4 *>(lp + wbl[k] + SLOT * CSLOTB);
-            if ((wbvalid >> k) & 1u) __builtin_amdgcn_raw_buffer_store_b128(x, rt, (int)wbg[k], 0, 16 /* sc1 */);
-        }
+        for (int k = 0; k < 4; k++)
+            if ((wbvalid >> k) & 1u) __builtin_amdgcn_raw_buffer_store_b128(x[k], rt, (int)wbg[k], 0, 16 /* sc1 */);
     } else {
 #pragma unroll
-        for (int k = 0; k < 4; k++) {
-            const col_u4 x = *reinterpret_cast<__attribute__((address_space(3))) const col_u4 *>(lp + wbl[k] + SLOT * CSLOTB);
-            __builtin_amdgcn_raw_buffer_store_b128(x, rt, (int)wbg[k], 0, 16 /* sc1 */);
-        }
+        for (int k = 0; k < 4; k++) __builtin_amdgcn_raw_buffer_store_b128(x[k], rt, (int)wbg[k], 0, 16 /* sc1 */);
     }
 }
 
@@ -443,8 +447,7 @@ column_solve_kernel(const ColumnSolve P)
         ColConst cc;
         cc.ha = col_f2{P.h[0], P.h[1]};
         cc.hb = col_f2{P.h[4], P.h[5]};
-        cc.hzu = sz > 0 ? P.h[2] : P.h[3];
-        cc.hzd = sz > 0 ? P.h[3] : P.h[2];
+        cc.hz = P.h[2];
         cc.sigact = (I * TILE_X + ci < L.n[0] && J * TILE_Y + cj < L.n[1]) ? sig : 0x3fffffff;
 
         // ---- the progress words of this column (lane 0), its upwind (1, 2) and downwind (3, 4) neighbours
@@ -553,8 +556,9 @@ column_solve_kernel(const ColumnSolve P)
             col_stage_any<0>(lp, cuni_ptr(vcol + zlo(0)), cuni_ptr(tcol + zlo(0)), goffv, gofft, lane, tvalid, zin(0), rim);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             ColRegs r;
-            r.vzu = CLDS_F(AX[CPER - 1] + CDX); r.tzu = CLDS_F(AX[CPER - 1] + CARRB + CDX);
+            r.tzu = CLDS_F(AX[CPER - 1] + CARRB + CDX);
             r.vc = CLDS_F(AX[0] + CDX); r.tc = CLDS_F(AX[0] + CARRB + CDX);
+            r.wz = cc.hz * (CLDS_F(AX[CPER - 1] + CDX) + r.vc);
             r.vn = CLDS_F(AX[1] + CDX); r.tn = CLDS_F(AX[1] + CARRB + CDX);
             r.va.x = CLDS_F(AX[0]); r.va.y = CLDS_F(AX[0] + CDX - CROWB);
             r.vb.x = CLDS_F(AX[0] + CDX + CROWB); r.vb.y = CLDS_F(AX[0] + 2 * CDX);
@@ -564,7 +568,9 @@ column_solve_kernel(const ColumnSolve P)
             CPROF_ADD(4, pr1 - pr0);
             unsigned long long prof_inwait = 0;
             (void)prof_inwait;
-            bool imp1 = false, imp2 = false;    // a cell improved in block j - 1 / j - 2
+            bool imp1 = false;                  // a cell improved in block j - 1
+            col_u4 wb[4];                       // chunk j - 1 on its way to the volume
+            bool wb_pending = false;
             bool late = false;                  // ... after the run had been closed
             bool closed = false;
             unsigned tilebits = 0;              // tiles of the run that improved (bit: tile index in the run)
@@ -573,9 +579,12 @@ column_solve_kernel(const ColumnSolve P)
 
 #define COL_BLOCK(JM)                                                                                              \
             {                                                                                                      \
-                /* ---- boundary j: chunk j - 2 is behind every lane, chunk j + 1 is wanted in 15 steps */         \
-                if (j >= 2 && CS * (j - 2) < wend && (imp1 || imp2))                                               \
-                    col_writeback<(JM + 1) % 3>(lp, cuni_ptr(tcol + zlo(j - 2)), wbg, wbl, wbvalid, rim);          \
+                /* ---- boundary j: chunk j - 2 is behind every lane (in registers, if it improved), chunk j + 1 is  \
+                   wanted in 15 steps */                                                                           \
+                if (wb_pending) {                                                                                  \
+                    col_wb_store(cuni_ptr(tcol + zlo(j - 2)), wbg, wb, wbvalid, rim);                              \
+                    wb_pending = false;                                                                            \
+                }                                                                                                  \
                 if ((j & 1) && j >= 3) pub_pending = k0 + (j - 1) / 2;      /* tile (j - 3) / 2 is complete */     \
                 if ((j & 1) && !closed) {                                                                          \
                     /* the first lane enters tile k0 + tr + 1 in 16 steps: is it part of the run? */              \
@@ -611,8 +620,12 @@ column_solve_kernel(const ColumnSolve P)
                     published = pub_pending;                                                                       \
                     pub_pending = -1;                                                                              \
                 }                                                                                                  \
+                /* (the last lane has just left chunk j - 1) */                                                    \
+                if (j >= 1 && CS * (j - 1) < wend && (imp1 || imp != 0ull)) {                                      \
+                    col_wb_read<(JM + 2) % 3>(lp, wbl, wb);                                                        \
+                    wb_pending = true;                                                                             \
+                }                                                                                                  \
                 ColSteps<CS * JM + CS - 2, 2>::run(lp, AX, r, cc, tb, span, imp);                                  \
-                imp2 = imp1;                                                                                       \
                 imp1 = imp != 0ull;                                                                                \
                 if (imp1) {                                                                                        \
                     tilebits |= 1u << (j >> 1);                                                                    \
@@ -643,14 +656,8 @@ column_solve_kernel(const ColumnSolve P)
             CPROF_ADD(13, j);
             prof_runs++;
             tilebits &= nt >= 32 ? ~0u : ((1u << nt) - 1u);
-            if (imp1 || imp2) {
-                // (chunk j - 2 = 2 nt - 1, the run's last one; j = 2 nt + 1: its slot is (j - 2) mod 3)
-                float *const dst = cuni_ptr(tcol + zlo(j - 2));
-                const int slot = (j - 2) % 3;
-                if (slot == 0) col_writeback<0>(lp, dst, wbg, wbl, wbvalid, rim);
-                else if (slot == 1) col_writeback<1>(lp, dst, wbg, wbl, wbvalid, rim);
-                else col_writeback<2>(lp, dst, wbg, wbl, wbvalid, rim);
-            }
+            // (chunk j - 2 = 2 nt - 1, the run's last one, was read in block j - 1 = 2 nt)
+            if (wb_pending) col_wb_store(cuni_ptr(tcol + zlo(j - 2)), wbg, wb, wbvalid, rim);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             mymask |= tilebits << k0;
             const int kend = k0 + nt;
@@ -677,10 +684,10 @@ column_solve_kernel(const ColumnSolve P)
         if (prof_runs == 0) CPROF_ADD(10, 1);
 
         // ---- seal: the column is done with sweep e
-        if (published < P.NK && lane == 0)
-            __hip_atomic_store(prog + col, ((unsigned long long)col_key(e, P.NK) << 32) | mymask, __ATOMIC_RELAXED,
-                               __HIP_MEMORY_SCOPE_AGENT);
         if (mymask != 0u) {
+            if (published < P.NK && lane == 0)      // (the downwind columns go on while the bits are being set)
+                __hip_atomic_store(prog + col, ((unsigned long long)col_key(e, P.NK) << 32) | mymask, __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_AGENT);
             // whoever comes EARLIER in this sweep's order and touches an improved tile has to look again: the
             // tile itself (other orderings), the tile below it in sweep order, the two upwind columns
             const unsigned own = mymask | (mymask >> 1);

@@ -356,6 +356,9 @@ static bool use_column(ttsweep_ctx *ctx, int nstart)
 {
     if (ctx->kernel != TTSWEEP_KERNEL_TILE || ctx->async_mode == 0) return false;
     if (!tile_star_is_six(ctx->tile_ent, ctx->tile_nent, ctx->tile_R)) return false;
+    // (the two z entries have one length - both stand for the same two star entries -: the column kernel carries the
+    // z edge of a cell to the next step, where it is the edge back)
+    if (ctx->tile_ent[2].h != ctx->tile_ent[3].h) return false;
     const DevLayout &L = ctx->L;
     const int NI = tile_count(L.n[0], TILE_X), NJ = tile_count(L.n[1], TILE_Y), NK = tile_count(L.n[2], TILE_Z);
     if (NK > COL_MAX_NK || NI > 32767 || NJ > 32767 || nstart > 32767) return false;
