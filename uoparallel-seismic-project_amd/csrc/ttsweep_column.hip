@@ -54,6 +54,14 @@ constexpr int CDX = (TILE_Y + 2) * CROWB;       // from an image row to its x + 
 constexpr int CPER = CS * CRING;                // steps of the ring period
 constexpr int CNDMA = (CNR * (CS / 4) + 63) / 64;      // LDS-DMA wave instructions per chunk and array (7)
 constexpr int CSIG = TILE_X + TILE_Y - 2;       // largest lane skew (14)
+// wavefronts of a workgroup: each works on its own column with its own rings, they never meet (no barrier); they are
+// ONE workgroup so that the CU places them on its four SIMDs, one each (single-wavefront workgroups land wherever the
+// dispatcher's round robin stands: two of four on one SIMD in some launches, and the launch is then 5 % slower)
+#ifndef TTSWEEP_COL_WG_WAVES
+#define TTSWEEP_COL_WG_WAVES 4
+#endif
+constexpr int CWG = TTSWEEP_COL_WG_WAVES;
+static_assert(CWG >= 1 && CWG <= COL_WAVES, "a workgroup's rings must fit the CU's LDS");
 static_assert(TILE_X == 8 && TILE_Y == 8 && TILE_Z == 2 * CS, "column pipelines: 8 x 8 x 32 tiles");
 static_assert(CARRB >= CRING * CSLOTB && CARRB % 256 == 0, "ring size");
 
@@ -115,7 +123,8 @@ struct ColConst {
 // One step: every lane relaxes one cell against its six neighbours.  Of its inputs only the travel times of the
 // four lateral neighbours can have been written in the previous step (by the two upwind lanes): they are read
 // first, behind that write; everything else arrived during the previous steps.
-template <int N>
+// FULL: every lane relaxes a cell of the run in this step (a block in the middle of a run): no activity test.
+template <int N, bool FULL>
 __device__ __forceinline__ void col_step(const lds_char lp, const int (&AX)[CPER], ColRegs &r, const ColConst &c, const int tb,
                                          const unsigned span, unsigned long long &imp)
 {
@@ -142,8 +151,10 @@ __device__ __forceinline__ void col_step(const lds_char lp, const int (&AX)[CPER
     float c0 = l0 + ta.x, c1 = l1 + ta.y, c2 = l2 + tb2.x, c3 = l3 + tb2.y;
     asm volatile("" : "+v"(c0), "+v"(c1), "+v"(c2), "+v"(c3));
     float best = fminf(fminf(pre, fminf(c0, c1)), fminf(c2, c3));
-    const bool act = (unsigned)(tb + (N % CS) - c.sigact) < span;      // (tb: the block's first step less the first cell)
-    best = act ? best : r.tc;
+    if (!FULL) {
+        const bool act = (unsigned)(tb + (N % CS) - c.sigact) < span;  // (tb: the block's first step less the first cell)
+        best = act ? best : r.tc;
+    }
     imp |= __ballot(best < r.tc);
     CLDS_W(a0 + CARRB + CDX) = best;
     r.wz = wzd; r.tzu = best;
@@ -153,17 +164,17 @@ __device__ __forceinline__ void col_step(const lds_char lp, const int (&AX)[CPER
     __builtin_amdgcn_sched_barrier(0);
 }
 
-template <int N0, int CNT>
+template <int N0, int CNT, bool FULL>
 struct ColSteps {
     static __device__ __forceinline__ void run(const lds_char lp, const int (&AX)[CPER], ColRegs &r, const ColConst &c,
                                                const int tb, const unsigned span, unsigned long long &imp)
     {
-        col_step<N0>(lp, AX, r, c, tb, span, imp);
-        ColSteps<N0 + 1, CNT - 1>::run(lp, AX, r, c, tb, span, imp);
+        col_step<N0, FULL>(lp, AX, r, c, tb, span, imp);
+        ColSteps<N0 + 1, CNT - 1, FULL>::run(lp, AX, r, c, tb, span, imp);
     }
 };
-template <int N0>
-struct ColSteps<N0, 0> {
+template <int N0, bool FULL>
+struct ColSteps<N0, 0, FULL> {
     static __device__ __forceinline__ void run(const lds_char, const int (&)[CPER], ColRegs &, const ColConst &, const int,
                                                const unsigned, unsigned long long &) {}
 };
@@ -248,7 +259,7 @@ struct ColWork {
 __device__ __forceinline__ void col_work_flush(const ColumnSolve &P, ColWork &w)
 {
     if (w.s >= 0 && w.tiles) {
-        unsigned long long *const slot = P.wgwork + ((size_t)blockIdx.x * P.nstart + w.s) * 2;
+        unsigned long long *const slot = P.wgwork + (((size_t)blockIdx.x * CWG + (threadIdx.x >> 6)) * P.nstart + w.s) * 2;
         slot[0] += w.cells * 6ull;
         slot[1] += w.tiles;
     }
@@ -362,16 +373,17 @@ void column_prof_dump()
 }
 #endif
 
-__global__ void __launch_bounds__(64)
+__global__ void __launch_bounds__(64 * CWG)
 column_solve_kernel(const ColumnSolve P)
 {
     extern __shared__ __attribute__((aligned(256))) char col_lds[];
-    const lds_char lp = (lds_char)col_lds;
-    const int lane = threadIdx.x;
+    const int lbase = cuni((int)(threadIdx.x >> 6)) * CLDSB;      // this wavefront's rings
+    const lds_char lp = (lds_char)col_lds + lbase;
+    const int lane = threadIdx.x & 63;
     const DevLayout &L = P.L;
     const long long clock0 = col_clock();
     const long long deadline = clock0 + P.timeout_ticks;
-    if ((unsigned)(unsigned long long)lp != 0u) {      // (CLDS_F: image offsets are used as LDS addresses)
+    if ((unsigned)(unsigned long long)lp != (unsigned)lbase) {      // (CLDS_F: image offsets are used as LDS addresses)
         col_fail(P, COL_ERR_LDS_BASE);
         return;
     }
@@ -441,7 +453,7 @@ column_solve_kernel(const ColumnSolve P)
             for (int n = 0; n < CPER; n++) {
                 const int wq = n - sig + (n < sig ? CPER : 0);
                 const int slot = wq >> 4, zc = wq & (CS - 1);
-                AX[n] = slot * CSLOTB + rxm * CROWB + (sz > 0 ? zc : CS - 1 - zc) * 4;
+                AX[n] = lbase + slot * CSLOTB + rxm * CROWB + (sz > 0 ? zc : CS - 1 - zc) * 4;
             }
         }
         ColConst cc;
@@ -492,6 +504,7 @@ column_solve_kernel(const ColumnSolve P)
         float *const tcol = cuni_ptr(P.tptr[s]) + (long long)(I * TILE_X - 1 + P.tpad) * P.ts0
                           + (long long)(J * TILE_Y - 1 + P.tpad) * P.ts1 + P.tlo;
         const int dx = min(TILE_X, L.n[0] - I * TILE_X), dy = min(TILE_Y, L.n[1] - J * TILE_Y);
+        const bool whole = dx == TILE_X && dy == TILE_Y;       // every lane's cell column lies inside the grid
         // rows of the image that do not exist in the caller's array (columns at the rim of the grid)
         unsigned tvalid = (1u << CNDMA) - 1u, wbvalid = 0xfu;
         const bool rim = P.tpad == 0 && (I == 0 || J == 0 || I * TILE_X + TILE_X + 1 > L.n[0] || J * TILE_Y + TILE_Y + 1 > L.n[1]);
@@ -611,7 +624,10 @@ column_solve_kernel(const ColumnSolve P)
                 const int tb = CS * j - wlo;                                                                       \
                 const unsigned span = (unsigned)max(whi() - wlo, 0);                                               \
                 unsigned long long imp = 0;                                                                        \
-                ColSteps<CS * JM, CS - 2>::run(lp, AX, r, cc, tb, span, imp);                                      \
+                /* (a block in the middle of a run, every cell column inside the grid: no lane is ever idle) */    \
+                const bool full = whole && tb >= CSIG && tb + CS - 1 < (int)span;                                  \
+                if (full) ColSteps<CS * JM, CS - 2, true>::run(lp, AX, r, cc, tb, span, imp);                      \
+                else ColSteps<CS * JM, CS - 2, false>::run(lp, AX, r, cc, tb, span, imp);                          \
                 /* (the block's last two steps read the next chunk: a lane's next cell but one, its neighbours' next) */ \
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                   \
                 if (pub_pending >= 0) {                                                                            \
@@ -625,7 +641,8 @@ column_solve_kernel(const ColumnSolve P)
                     col_wb_read<(JM + 2) % 3>(lp, wbl, wb);                                                        \
                     wb_pending = true;                                                                             \
                 }                                                                                                  \
-                ColSteps<CS * JM + CS - 2, 2>::run(lp, AX, r, cc, tb, span, imp);                                  \
+                if (full) ColSteps<CS * JM + CS - 2, 2, true>::run(lp, AX, r, cc, tb, span, imp);                  \
+                else ColSteps<CS * JM + CS - 2, 2, false>::run(lp, AX, r, cc, tb, span, imp);                      \
                 imp1 = imp != 0ull;                                                                                \
                 if (imp1) {                                                                                        \
                     tilebits |= 1u << (j >> 1);                                                                    \
@@ -758,18 +775,20 @@ column_init_kernel(ColumnSolve P, const StartDesc *__restrict__ starts, int from
     if (t == 0) { P.status[0] = COL_RUNNING; P.status[1] = (unsigned)P.nstart; }
 }
 
+int column_solve_wg_waves() { return CWG; }
+
 hipError_t column_solve_wgs_per_cu(int *wgs)
 {
     static bool raised = false;
     if (!raised) {
-        const hipError_t e = hipFuncSetAttribute((const void *)column_solve_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, CLDSB);
+        const hipError_t e = hipFuncSetAttribute((const void *)column_solve_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, CWG * CLDSB);
         if (e != hipSuccess) return e;
         raised = true;
     }
     int n = 0;
-    const hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, (const void *)column_solve_kernel, 64, CLDSB);
+    const hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, (const void *)column_solve_kernel, 64 * CWG, CWG * CLDSB);
     if (e != hipSuccess) return e;
-    *wgs = std::min(std::max(n, 1), (int)COL_WAVES);
+    *wgs = std::min(std::max(n, 1), (int)COL_WAVES / CWG);
     return hipSuccess;
 }
 
@@ -788,7 +807,7 @@ hipError_t launch_column_solve(const ColumnSolve &P, int nblocks, hipStream_t st
         || P.L.p[2] - P.L.lo[2] - P.NK * TILE_Z < CS || !P.tptr || P.ts1 % CS || P.ts0 % CS || P.tlo % CS
         || (P.tpad != 0 && P.tpad != 1) || (P.tpad == 0 && P.L.n[2] % TILE_Z))
         return hipErrorInvalidValue;
-    hipLaunchKernelGGL(column_solve_kernel, dim3((unsigned)nblocks), dim3(64), CLDSB, st, P);
+    hipLaunchKernelGGL(column_solve_kernel, dim3((unsigned)nblocks), dim3(64 * CWG), CWG * CLDSB, st, P);
     return hipGetLastError();
 }
 

@@ -459,9 +459,10 @@ static int solve_column(ttsweep_ctx *ctx, int nstart, bool from_box, float *cons
     if (!ctx->h_col_status) HIPCHK(hipHostMalloc((void **)&ctx->h_col_status, 8 * sizeof(unsigned)));
     // the resident grid: no more workgroups than a sweep has columns (a workgroup that finds nothing to do waits
     // inside a later sweep), whole rounds of the sequences
-    long long blocks = std::min<long long>(ctx->col_blocks, (long long)ncol * nstart);
+    const int wgw = column_solve_wg_waves();
+    long long blocks = std::min<long long>(ctx->col_blocks, ((long long)ncol * nstart + wgw - 1) / wgw);
     blocks = std::max<long long>(blocks / C.nseq, 1) * C.nseq;
-    const size_t need = (size_t)blocks * (size_t)nstart * 2;
+    const size_t need = (size_t)blocks * wgw * (size_t)nstart * 2;
     if (need > ctx->tile_wgwork_cap) {
         if (ctx->d_tile_wgwork) HIPCHK(hipFree(ctx->d_tile_wgwork));
         ctx->d_tile_wgwork = nullptr;
@@ -509,7 +510,7 @@ static int solve_column(ttsweep_ctx *ctx, int nstart, bool from_box, float *cons
         any |= (ctx->h_changed[s] & CHANGED_IMPROVED) != 0;
         sweeps[s] = ctx->h_col_done[s];
     }
-    ctx->tile_blocks_used = (int)blocks;
+    ctx->tile_blocks_used = (int)blocks * wgw;
     return any ? 1 : 0;
 }
 

@@ -116,8 +116,9 @@ hipError_t launch_init_tile_state(const DevLayout &L, const StartDesc &sd, bool 
 bool tile_star_is_six(const TileEntry *ent, int nent, int R);
 // first state: every column sealed in "sweep 0", the tiles around a start due (from_box: every tile)
 hipError_t launch_column_init(const ColumnSolve &P, const StartDesc *starts, bool from_box, hipStream_t st);
-hipError_t column_solve_wgs_per_cu(int *wgs);       // single-wavefront workgroups a CU holds (and the LDS opt-in)
-// the whole solve: `nblocks` resident single-wavefront workgroups claim columns until every start is at rest
+hipError_t column_solve_wgs_per_cu(int *wgs);   // workgroups a CU holds (and the LDS opt-in)
+int column_solve_wg_waves();                    // wavefronts (columns in flight) of one workgroup
+// the whole solve: the wavefronts of `nblocks` resident workgroups claim columns until every start is at rest
 hipError_t launch_column_solve(const ColumnSolve &P, int nblocks, hipStream_t st);
 
 #ifdef TTSWEEP_TILE_PROFILE
