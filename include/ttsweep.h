@@ -140,6 +140,11 @@ typedef struct ttsweep_ctx ttsweep_ctx;
                                          whole tiles long (nz % 32 == 0) and 64-byte aligned - no padded copy, no copy
                                          back; 0 = always in the library's padded volumes */
 
+#define TTSWEEP_OPT_QUEUES 20        /* schedule only, never the result: unit queues / planner rings / claim sequences of
+                                         a solve, 1 .. 8 (default: the XCDs the device shows, counted at create - 8 on a
+                                         whole MI355X, fewer on a partition).  A one-launch solve serves at most 32 starts
+                                         per ring: with more starts per queue than that the launch-per-pass driver runs */
+
 #define TTSWEEP_KERNEL_AUTO       0
 #define TTSWEEP_KERNEL_CELL       1   /* one thread per cell, star from global memory */
 #define TTSWEEP_KERNEL_STRIP      2   /* LDS-staged plane slabs, register strips */

@@ -933,6 +933,65 @@ def test_many_starts_on_a_small_grid(P, nstart):
         assert_bit_equal(a, b, f"{nstart} starts")
 
 
+@pytest.mark.parametrize("queues,nstart,one_launch", [(1, 32, True), (1, 40, False), (2, 64, True), (2, 70, False)])
+def test_starts_per_ring_limit_with_few_queues(P, queues, nstart, one_launch):
+    """A device (or partition) with fewer than 8 XCDs has fewer planner rings, and a ring serves at most 32 starts:
+    beyond that the launch-per-pass driver has to run - not an error (TTSWEEP_OPT_QUEUES forces the queue count
+    the census would find there).  Both drivers against the CELL kernel, bit for bit."""
+    rng = np.random.default_rng(79)
+    shape = (21, 18, 12)
+    v = rng.uniform(0.2, 1.0, size=shape).astype(np.float32)
+    fs = P.inputs.make_fs(P.inputs.read_triples(P.inputs.star_path("3")))
+    starts = np.stack([rng.integers(0, n, size=nstart) for n in shape], axis=1).astype(np.int32)
+    ref, _, _ = gpu_converge(P, v, fs, starts, kernel=1)
+    with P.TravelTimeSolver(shape, fs) as sol:
+        sol.set_option(P.OPT_KERNEL, 2)
+        sol.set_option(P.OPT_QUEUES, queues)
+        sol.set_velocity(v)
+        got = _boxes(shape, starts)
+        assert sol.solve(starts, got) == 1
+        st = sol.stats()
+        assert st["kernel_variant"] == 2 and st["fallbacks"] == 0 and (st["launches"] == 1) == one_launch
+    for a, b in zip(got, ref):
+        assert_bit_equal(a, b, f"{nstart} starts, {queues} queue(s)")
+    with pytest.raises(Exception):
+        with P.TravelTimeSolver(shape, fs) as sol:
+            sol.set_option(P.OPT_QUEUES, 9)
+
+
+def test_column_rest_is_declared_once_per_start(P):
+    """Three starts that come to rest in different sweeps, many times over: successive sweeps of the column driver
+    overlap, and two of them can both end without an improvement before either hears of the other - the start
+    must still count as ONE finished start (counted twice, the launch ended while the third start was still being
+    relaxed: 9 cells short of the fixed point in two of five runs)."""
+    import torch
+    shape, seed = (40, 24, 160), 56
+    rng = np.random.default_rng(seed)
+    v = rng.uniform(0.1, 0.5, size=shape).astype(np.float32)
+    fs = P.inputs.make_fs(P.inputs.read_triples(P.inputs.star_path("six")))
+    nstart = int(rng.integers(1, 4))
+    starts = np.stack([rng.integers(0, n, size=nstart) for n in shape], axis=1).astype(np.int32)
+    assert nstart == 3
+    dev = torch.device("cuda:0")
+    with P.TravelTimeSolver(shape, fs) as ref:
+        ref.set_option(P.OPT_KERNEL, 3)
+        ref.set_option(P.OPT_ASYNC, 0)
+        ref.set_velocity(v)
+        want = torch.empty((nstart,) + shape, dtype=torch.float32, device=dev)
+        assert ref.solve_device(starts, want, init=True) == 1
+    for in_place in (1, 0):
+        with P.TravelTimeSolver(shape, fs) as sol:
+            sol.set_option(P.OPT_KERNEL, 3)
+            sol.set_option(P.OPT_TILE_IN_PLACE, in_place)
+            sol.set_velocity(v)
+            for rep in range(40):
+                tt = torch.empty((nstart,) + shape, dtype=torch.float32, device=dev)
+                assert sol.solve_device(starts, tt, init=True) == 1
+                st = sol.stats()
+                assert st["launches"] == 1 and st["fallbacks"] == 0
+                assert torch.equal(tt, want), f"repetition {rep}, in place {in_place}"
+
+
 def test_converged_box_with_one_finite_unit_reports_no_change(P, oracle):
     """A star that only moves along z reaches one z-column: every finite cell sits in ONE
     activity unit, which is exactly the case the distance gate treats as "grown from one

@@ -302,6 +302,11 @@ int ttsweep_set_option(ttsweep_ctx *ctx, int key, long long value)
         ctx->async_window = (float)((double)value / 1000.0);
         return 0;
     case TTSWEEP_OPT_TILE_IN_PLACE: ctx->col_in_place_off = value == 0; return 0;
+    case TTSWEEP_OPT_QUEUES:
+        if (value < 1 || value > ttsweep::UNITQ_LISTS) return set_error("queues must be 1 .. %d", (int)ttsweep::UNITQ_LISTS);
+        ctx->nlists = (int)value;
+        ctx->unitq_blocks = 0;          // (the grid is whole rounds of the queues: sized again at the next solve)
+        return 0;
     case TTSWEEP_OPT_ASYNC_SPECIAL:
         if (value < 1) return set_error("dead-edge interval must be positive");
         ctx->async_special_every = (int)std::min<long long>(value, 1 << 30);
