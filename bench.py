@@ -136,6 +136,7 @@ def workload_args(args):
         (["--async-mode", str(args.async_mode)] if args.async_mode is not None else []) + \
         (["--async-gate", str(args.async_gate)] if args.async_gate is not None else []) + \
         (["--defer-margin", str(args.defer_margin)] if args.defer_margin is not None else []) + \
+        (["--inunit", str(args.inunit)] if args.inunit is not None else []) + \
         (["--prepass", str(args.prepass)] if args.prepass else []) + \
         (["--lib", args.lib] if args.lib else [])
 
@@ -245,7 +246,7 @@ def hbm_regime_wanted(args):
 def hbm_regime_args(args):
     a = argparse.Namespace(**vars(args))
     a.grid, a.star, a.starts, a.nstarts = (HBM_REGIME[k] for k in ("grid", "star", "starts", "nstarts"))
-    a.gate_speed = a.pair_min_starts = a.async_mode = a.async_gate = a.defer_margin = None
+    a.gate_speed = a.pair_min_starts = a.async_mode = a.async_gate = a.defer_margin = a.inunit = None
     a.prepass = 0
     return a
 
@@ -337,6 +338,7 @@ def main():
     ap.add_argument("--async-mode", type=int, default=None, choices=[-1, 0, 1],
                     help="schedule knob of the STRIP kernel: 1 one launch per solve, 0 a launch pair per pass, -1 library default")
     ap.add_argument("--async-gate", type=float, default=None, help="schedule knob: cells per round by which the gate of a one-launch solve opens")
+    ap.add_argument("--inunit", type=int, default=None, help="schedule knob: passes of a unit that improved against its own planes (one-launch STRIP solve)")
     ap.add_argument("--defer-margin", type=float, default=None,
                     help="schedule knob: improvements are told at once only to units not nearer to the start by more than this (cells)")
     ap.add_argument("--prepass", type=int, default=0,
@@ -444,6 +446,8 @@ def main():
         sol.set_option(P.OPT_ASYNC_GATE_MILLI, int(round(args.async_gate * 1000)))
     if args.defer_margin is not None:
         sol.set_option(P.OPT_DEFER_MARGIN_MILLI, int(round(args.defer_margin * 1000)))
+    if args.inunit is not None:
+        sol.set_option(P.OPT_ASYNC_INUNIT, args.inunit)
     sol.set_velocity(v_dev)
     if args.prepass:
         sol.set_option(P.OPT_PREPASS_ENTRIES, args.prepass)

@@ -145,6 +145,11 @@ typedef struct ttsweep_ctx ttsweep_ctx;
                                          whole MI355X, fewer on a partition).  A one-launch solve serves at most 32 starts
                                          per ring: with more starts per queue than that the launch-per-pass driver runs */
 
+#define TTSWEEP_OPT_ASYNC_INUNIT 21   /* schedule only, never the result (STRIP kernel, one launch per solve): how often
+                                         a unit that improved is relaxed again, at once, against its OWN planes - the
+                                         values it has just stored - before it is handed back (-1, the default: 2 for
+                                         solves of 2 and more starts, 0 for a single start; 0 .. 8) */
+
 #define TTSWEEP_KERNEL_AUTO       0
 #define TTSWEEP_KERNEL_CELL       1   /* one thread per cell, star from global memory */
 #define TTSWEEP_KERNEL_STRIP      2   /* LDS-staged plane slabs, register strips */
@@ -180,11 +185,14 @@ int ttsweep_set_option(ttsweep_ctx *ctx, int key, long long value);
 /* Velocity volume (the global `vbox.box.flat`, :65), host or device memory,
  * FLOATBOX layout.  The library keeps its own device copy.  Every value must be finite
  * and >= 0 (zero is accepted as the reference accepts it; a negative velocity, for which
- * the reference's loop :151-170 need not terminate, Inf and NaN are refused: < 0), and a
- * positive value must be at least 2^-124 / (smallest fs[].d of the star) - about 4.7e-39
- * for the reference's delta of 10 -: below that a delay d * (v[c] + v[o]) can be a denormal
- * number, where the reference's "/ 2.0" of the rounded product (:216) and the kernels'
- * multiplication by d / 2 no longer agree in the last bit; such volumes are refused too. */
+ * the reference's loop :151-170 need not terminate, Inf and NaN are refused: < 0).
+ * A volume with a positive value below 2^-124 / (smallest fs[].d of the star) - about 4.7e-39
+ * for the reference's delta of 10 - is accepted and solved bit for bit like every other, but
+ * slowly: there a delay d * (v[c] + v[o]) can be a denormal number, where the reference's
+ * "/ 2.0" of the rounded product (:216) and the fast kernels' multiplication by d / 2 no
+ * longer agree in the last bit, so such a volume goes to the per-cell kernel's instance that
+ * rounds as the reference does (ttsweep_stats.kernel_variant reads TTSWEEP_KERNEL_CELL, whatever
+ * TTSWEEP_OPT_KERNEL asked for; the next volume without such values gets the chosen kernel back). */
 int ttsweep_set_velocity(ttsweep_ctx *ctx, const float *v_host);
 int ttsweep_set_velocity_device(ttsweep_ctx *ctx, const float *v_dev);
 

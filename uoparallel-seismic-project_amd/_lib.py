@@ -82,6 +82,7 @@ OPT_GATE_SPEED_MILLI, OPT_GATE_R0_MILLI, OPT_PAIR_MIN_STARTS, OPT_PREPASS_ENTRIE
 OPT_ASYNC, OPT_ASYNC_LOW, OPT_ASYNC_HIGH, OPT_ASYNC_SPECIAL, OPT_ASYNC_POLICY, OPT_DEFER_MARGIN_MILLI, OPT_ASYNC_WINDOW_MILLI, OPT_ASYNC_GATE_MILLI, OPT_ASYNC_GATE_FAST_MILLI, OPT_ASYNC_TIMEOUT_MILLI = 9, 10, 11, 12, 13, 14, 15, 16, 17, 18
 OPT_TILE_IN_PLACE = 19
 OPT_QUEUES = 20
+OPT_ASYNC_INUNIT = 21
 KERNEL_AUTO, KERNEL_CELL, KERNEL_STRIP, KERNEL_TILE = 0, 1, 2, 3
 
 

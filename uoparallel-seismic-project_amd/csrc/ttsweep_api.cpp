@@ -222,6 +222,30 @@ void ttsweep_destroy(ttsweep_ctx *ctx)
     delete ctx;
 }
 
+// the padded layout depends on the kernel: rebuild it and drop the device copies
+static int switch_kernel(ttsweep_ctx *ctx, int k)
+{
+    if (k == ctx->kernel) return 0;
+    if (ctx_bind(ctx)) return -1;
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    ctx->kernel = k;
+    make_layout(ctx);
+    HIPCHK(hipFree(ctx->d_v));
+    ctx->d_v = nullptr;
+    if (ctx->d_vface) HIPCHK(hipFree(ctx->d_vface));
+    ctx->d_vface = nullptr;
+    ctx->have_v = false;
+    if (ctx->d_T) HIPCHK(hipFree(ctx->d_T));
+    ctx->d_T = nullptr;
+    ctx->capacity_starts = 0;
+    ctx->unit_order_key.assign(ctx->unit_order_key.size(), -1);     // orders belong to the old layout
+    ctx->async_list_key.clear();
+    HIPCHK(hipMalloc((void **)&ctx->d_v, (size_t)ctx->L.cells * sizeof(float)));
+    if (upload_star(ctx)) return -1;
+    if (k == TTSWEEP_KERNEL_STRIP && upload_strip_plan(ctx)) return -1;
+    return 0;
+}
+
 int ttsweep_set_option(ttsweep_ctx *ctx, int key, long long value)
 {
     if (!ctx) return set_error("null context");
@@ -232,26 +256,11 @@ int ttsweep_set_option(ttsweep_ctx *ctx, int key, long long value)
         if (k == TTSWEEP_KERNEL_AUTO) k = auto_kernel(ctx);
         if (!kernel_available(ctx, k))
             return set_error("kernel variant %lld not available for this star", value);
-        if (k == ctx->kernel) return 0;
-        // the padded layout depends on the kernel: rebuild it and drop device copies
-        if (ctx_bind(ctx)) return -1;
-        HIPCHK(hipStreamSynchronize(ctx->stream));
-        ctx->kernel = k;
-        make_layout(ctx);
-        HIPCHK(hipFree(ctx->d_v));
-        ctx->d_v = nullptr;
-        if (ctx->d_vface) HIPCHK(hipFree(ctx->d_vface));
-        ctx->d_vface = nullptr;
-        ctx->have_v = false;
-        if (ctx->d_T) HIPCHK(hipFree(ctx->d_T));
-        ctx->d_T = nullptr;
-        ctx->capacity_starts = 0;
-        ctx->unit_order_key.assign(ctx->unit_order_key.size(), -1);     // orders belong to the old layout
-        ctx->async_list_key.clear();
-        HIPCHK(hipMalloc((void **)&ctx->d_v, (size_t)ctx->L.cells * sizeof(float)));
-        if (upload_star(ctx)) return -1;
-        if (k == TTSWEEP_KERNEL_STRIP && upload_strip_plan(ctx)) return -1;
-        return 0;
+        if (ctx->exact_half) {          // (a velocity volume with sub-limit values: the CELL kernel's exact instance stays)
+            ctx->kernel_wanted = k;
+            return 0;
+        }
+        return switch_kernel(ctx, k);
     }
     case TTSWEEP_OPT_MAX_SWEEPS:
         if (value <= 0) return set_error("max sweeps must be positive");
@@ -302,6 +311,10 @@ int ttsweep_set_option(ttsweep_ctx *ctx, int key, long long value)
         ctx->async_window = (float)((double)value / 1000.0);
         return 0;
     case TTSWEEP_OPT_TILE_IN_PLACE: ctx->col_in_place_off = value == 0; return 0;
+    case TTSWEEP_OPT_ASYNC_INUNIT:
+        if (value < -1 || value > 8) return set_error("in-unit passes must be -1 (default rule) or 0 .. 8");
+        ctx->async_inunit = (int)value;
+        return 0;
     case TTSWEEP_OPT_QUEUES:
         if (value < 1 || value > ttsweep::UNITQ_LISTS) return set_error("queues must be 1 .. %d", (int)ttsweep::UNITQ_LISTS);
         ctx->nlists = (int)value;
@@ -352,16 +365,18 @@ int ttsweep_set_velocity_device(ttsweep_ctx *ctx, const float *v_dev)
     // every cell must be a finite number >= 0: delays are then >= 0, the relaxation has a least
     // fixed point and no NaN can arise.  Zero is accepted, as the
     // reference accepts it (zero delays: serial_new/sweep-tt-multistart.c:216 has no test);
-    // a negative velocity would make the reference loop forever and is refused here.  So are
-    // positive velocities so small that a delay could be a denormal number: the reference
-    // halves the ROUNDED product d * (v[c] + v[o]) (:216), the kernels multiply by d / 2, and
-    // the two differ in the last bit once the product is denormal (found by the test that now
-    // pins this rule: tests/test_gpu_parity.py::test_tiny_velocities).  With the smallest
-    // offset length d_min every product is >= 2^-124 when v >= 2^-124 / d_min (a factor two above
-    // the smallest product that halves exactly).
-    unsigned long long *d_bad = ctx->d_scratch, h_bad = 0;
+    // a negative velocity would make the reference loop forever and is refused here.
+    // Positive velocities so small that a delay could be a denormal number: the reference
+    // halves the ROUNDED product d * (v[c] + v[o]) (:216), the fast kernels multiply by d / 2, and
+    // the two differ in the last bit once the product is denormal (found by
+    // tests/test_gpu_parity.py::test_tiny_velocities).  With the smallest offset length d_min every
+    // product is >= 2^-124 when v >= 2^-124 / d_min (a factor two above the smallest product that
+    // halves exactly).  A volume with a positive value below that is accepted all the same and solved
+    // by the CELL kernel's EXACT instance, which rounds as the reference does (product, then half):
+    // slow, but what the reference accepts the boundary accepts, with the same bits.
+    unsigned long long *d_bad = ctx->d_scratch, h_bad[2] = {0, 0};
     const long long n = (long long)ctx->nx * ctx->ny * ctx->nz;
-    HIPCHK(hipMemsetAsync(d_bad, 0, sizeof(unsigned long long), ctx->stream));
+    HIPCHK(hipMemsetAsync(d_bad, 0, 2 * sizeof(unsigned long long), ctx->stream));
     float tiny = 0.0f;
     {
         float dmin = 0.0f;
@@ -372,7 +387,23 @@ int ttsweep_set_velocity_device(ttsweep_ctx *ctx, const float *v_dev)
         if (dmin > 0.0f) tiny = (float)std::min(std::ldexp(1.0, -124) / (double)dmin, 1.0e30);
     }
     HIPCHK(launch_count_bad_velocity(v_dev, n, tiny, d_bad, ctx->stream));
-    HIPCHK(hipMemcpyAsync(&h_bad, d_bad, sizeof h_bad, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipMemcpyAsync(h_bad, d_bad, sizeof h_bad, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    if (h_bad[0]) {
+        ctx->have_v = false;
+        return set_error("velocity volume holds %llu cells that are negative or not finite", h_bad[0]);
+    }
+    const bool exact = h_bad[1] != 0;
+    if (exact != ctx->exact_half) {
+        if (exact) {
+            ctx->kernel_wanted = ctx->kernel;
+            if (switch_kernel(ctx, TTSWEEP_KERNEL_CELL)) return -1;
+            ctx->exact_half = true;
+        } else {
+            ctx->exact_half = false;
+            if (switch_kernel(ctx, ctx->kernel_wanted)) return -1;
+        }
+    }
     HIPCHK(launch_pack(ctx->L, v_dev, ctx->d_v, 0.0f, ctx->stream));
     if (ctx->kernel == TTSWEEP_KERNEL_TILE) {
         if (!ctx->d_vface)
@@ -380,12 +411,6 @@ int ttsweep_set_velocity_device(ttsweep_ctx *ctx, const float *v_dev)
         HIPCHK(launch_build_tile_faces(ctx->L, ctx->d_v, ctx->d_vface, ctx->tile_fz, ctx->stream));
     }
     HIPCHK(hipStreamSynchronize(ctx->stream));
-    if (h_bad) {
-        ctx->have_v = false;
-        return set_error("velocity volume holds %llu cells that are negative, not finite, or positive but below "
-                         "%.3g (delays would be denormal numbers, where bit parity with the reference ends)",
-                         h_bad, (double)tiny);
-    }
     ctx->have_v = true;
     if (ctx->pre && ttsweep_set_velocity_device(ctx->pre, v_dev) < 0) return -1;
     return 0;
@@ -715,7 +740,7 @@ int ttsweep_validate_device(ttsweep_ctx *ctx, const ttsweep_start *start, const 
     HIPCHK(hipMemsetAsync(d_counts, 0, 3 * sizeof(unsigned long long), ctx->stream));
     HIPCHK(launch_pack(L, tt_dev, ctx->d_T, INFINITY, ctx->stream));
     HIPCHK(launch_validate(L, ctx->d_v, ctx->d_T, sidx, ctx->d_fwd_entries, ctx->n_fwd_entries,
-                           ctx->d_cell_entries, ctx->n_cell_entries, d_counts, ctx->stream));
+                           ctx->d_cell_entries, ctx->n_cell_entries, d_counts, ctx->exact_half, ctx->stream));
     unsigned long long h[3] = {0, 0, 0};
     HIPCHK(hipMemcpyAsync(h, d_counts, sizeof h, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));

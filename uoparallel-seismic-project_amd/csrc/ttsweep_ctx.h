@@ -61,6 +61,9 @@ struct ttsweep_ctx {
 
     float *d_v = nullptr;                   // padded velocity
     bool have_v = false;
+    int async_inunit = -1;                      // in-unit passes of a one-launch STRIP solve (-1: by the number of starts)
+    bool exact_half = false;                    // the velocity volume holds sub-limit values: CELL kernel, reference rounding
+    int kernel_wanted = 0;                      // ... and the kernel to go back to when a volume without them arrives
     unsigned long long *d_scratch = nullptr;    // four counters for one-off kernels (velocity check, validator)
     CellEntry *d_cell_entries = nullptr;
     int n_cell_entries = 0;

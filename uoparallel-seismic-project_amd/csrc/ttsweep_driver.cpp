@@ -172,7 +172,7 @@ static int launch_pass(ttsweep_ctx *ctx, int nactive, int nstart, int *d_changed
         if (launch_pass_tile(ctx, nactive, d_changed)) return -1;
     } else {
         HIPCHK(launch_sweep_cell(ctx->L, ctx->d_v, ctx->d_starts, ctx->d_active, nactive,
-                                 d_changed, ctx->d_cell_entries, ctx->n_cell_entries,
+                                 d_changed, ctx->d_cell_entries, ctx->n_cell_entries, ctx->exact_half,
                                  ctx->stream));
     }
     if (ctx->timing && timed_event(ctx, &e1)) return -1;
@@ -262,6 +262,10 @@ static int solve_async_strip(ttsweep_ctx *ctx, int nstart, std::vector<int> &swe
     }
     if (!cached) as.ring_start_off[as.nrings] = (int)ring_starts.size();
     as.scan_slack = 16384 * ((nstart + as.nrings - 1) / as.nrings);
+    // a unit that improved is relaxed again against its own planes, at once (measured: 24 starts 34.5 -> 29.4 ms with
+    // two such passes - the planner hands out a third less -, 3 starts 7.85 -> 7.77, one start 6.38 -> 6.52:
+    // profiles/r04_inunit.txt)
+    as.inunit = ctx->async_inunit >= 0 ? ctx->async_inunit : (nstart >= 2 ? 2 : 0);
     if (!cached && flat.size() > ctx->async_list_cap) {
         if (ctx->d_async_list) HIPCHK(hipFree(ctx->d_async_list));
         ctx->d_async_list = nullptr;

@@ -26,23 +26,24 @@ hipError_t launch_unpack_batch(const DevLayout &L, const float *padded0, float *
 // *seen |= 1 << (XCD id) for every workgroup of an `nblocks`-workgroup launch
 hipError_t launch_xcc_census(unsigned *seen, int nblocks, hipStream_t st);
 // *bad += cells of the caller's n-cell velocity volume that are negative, not finite, or
-// positive but below `tiny`
+// positive but below `tiny` (bad[1]; bad[0]: negative, infinite, NaN)
 hipError_t launch_count_bad_velocity(const float *v, long long n, float tiny, unsigned long long *bad, hipStream_t st);
 
 // ---- sweep, variant CELL ---------------------------------------------------
 // One chaotic in-place pull pass over the whole grid for the `nactive` starts
 // listed in `active`; changed[s] is OR-ed with 1 when any cell of start s
-// improved.
+// improved.  exact: delays rounded as the reference rounds them - product first, then halved - for velocity
+// volumes whose products can be denormal numbers (ttsweep_set_velocity decides).
 hipError_t launch_sweep_cell(const DevLayout &L, const float *v, const StartDesc *starts,
                              const int *active, int nactive, int *changed,
-                             const CellEntry *entries, int nentries, hipStream_t st);
+                             const CellEntry *entries, int nentries, bool exact, hipStream_t st);
 
 // ---- validator: counts[0] += (cell, forward entry) pairs a reference sweep would still
 // store through, counts[1] += cells still at +INFINITY, counts[2] += cells whose travel
 // time no live edge can have produced (T is one padded volume)
 hipError_t launch_validate(const DevLayout &L, const float *v, const float *T, long long sidx,
                            const FwdEntry *entries, int nentries, const CellEntry *cell_entries,
-                           int ncell_entries, unsigned long long *counts, hipStream_t st);
+                           int ncell_entries, unsigned long long *counts, bool exact, hipStream_t st);
 
 // ---- sweep, variant STRIP --------------------------------------------------
 // Same contract as launch_sweep_cell, but cells inside a start's dead-edge box

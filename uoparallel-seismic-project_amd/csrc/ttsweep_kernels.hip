@@ -233,15 +233,19 @@ hipError_t launch_xcc_census(unsigned *seen, int nblocks, hipStream_t st)
 __global__ void __launch_bounds__(256)
 count_bad_velocity_kernel(const float *__restrict__ v, long long n, unsigned tiny_bits, unsigned long long *__restrict__ bad)
 {
-    unsigned mine = 0;
+    unsigned mine = 0, mine_small = 0;
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
         const unsigned bits = __float_as_uint(v[i]);
-        const bool ok = bits == 0u || bits == 0x80000000u || (bits >= tiny_bits && bits < 0x7f800000u);
+        const bool zero = bits == 0u || bits == 0x80000000u;
+        const bool small = !zero && bits < tiny_bits;               // (positive: the sign bit makes a number large)
+        const bool ok = zero || bits < 0x7f800000u;
         mine += !ok;
+        mine_small += small;
     }
 #pragma unroll
-    for (int w = 32; w >= 1; w >>= 1) mine += __shfl_xor(mine, w);
+    for (int w = 32; w >= 1; w >>= 1) { mine += __shfl_xor(mine, w); mine_small += __shfl_xor(mine_small, w); }
     if ((threadIdx.x & 63) == 0 && mine) atomicAdd(bad, (unsigned long long)mine);
+    if ((threadIdx.x & 63) == 0 && mine_small) atomicAdd(bad + 1, (unsigned long long)mine_small);
 }
 
 hipError_t launch_count_bad_velocity(const float *v, long long n, float tiny, unsigned long long *bad, hipStream_t st)
@@ -273,6 +277,21 @@ hipError_t launch_count_bad_velocity(const float *v, long long n, float tiny, un
 constexpr int CELL_BX = 64;     // lanes along the stride-1 axis c
 constexpr int CELL_BY = 4;      // rows of b per block
 
+// EXACT: the reference's own rounding of a delay - the product d (v[c] + v[o]) rounded, THEN halved
+// (serial_new/sweep-tt-multistart.c:216) - for velocity volumes with values so small that the product can be a
+// denormal number, where d / 2 times the sum rounds differently (h + h = d exactly).
+template <bool EXACT>
+__device__ __forceinline__ float edge_delay(float h, float sum)
+{
+    if (EXACT) {
+        float p = (h + h) * sum;
+        asm volatile("" : "+v"(p));     // (the product is rounded before it is halved)
+        return p * 0.5f;
+    }
+    return h * sum;
+}
+
+template <bool EXACT>
 __global__ void __launch_bounds__(CELL_BX *CELL_BY)
 sweep_cell_kernel(DevLayout L, const float *__restrict__ v,
                   const StartDesc *__restrict__ starts, const int *__restrict__ active,
@@ -306,7 +325,7 @@ sweep_cell_kernel(DevLayout L, const float *__restrict__ v,
             const bool live = ((en.flags & PULL_FWD) && !c_is_start)
                            || ((en.flags & PULL_REV) && oi != sd.sidx);
             const float sum = vc + v[oi];
-            const float delay = en.h * sum;
+            const float delay = edge_delay<EXACT>(en.h, sum);
             const float cand = delay + T[oi];
             if (live && cand < best) best = cand;
         }
@@ -321,15 +340,15 @@ sweep_cell_kernel(DevLayout L, const float *__restrict__ v,
 
 hipError_t launch_sweep_cell(const DevLayout &L, const float *v, const StartDesc *starts,
                              const int *active, int nactive, int *changed,
-                             const CellEntry *entries, int nentries, hipStream_t st)
+                             const CellEntry *entries, int nentries, bool exact, hipStream_t st)
 {
     const int cblocks = (L.n[2] + CELL_BX - 1) / CELL_BX;
     const int bblocks = (L.n[1] + CELL_BY - 1) / CELL_BY;
     const long long nblocks = (long long)nactive * L.n[0] * bblocks * cblocks;
     if (nblocks <= 0) return hipSuccess;
     if (nblocks > 0x7fffffffLL) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(sweep_cell_kernel, dim3((unsigned)nblocks), dim3(CELL_BX, CELL_BY), 0, st,
-                       L, v, starts, active, changed, entries, nentries, cblocks, bblocks);
+    hipLaunchKernelGGL(exact ? sweep_cell_kernel<true> : sweep_cell_kernel<false>, dim3((unsigned)nblocks),
+                       dim3(CELL_BX, CELL_BY), 0, st, L, v, starts, active, changed, entries, nentries, cblocks, bblocks);
     return hipGetLastError();
 }
 
@@ -341,6 +360,7 @@ hipError_t launch_sweep_cell(const DevLayout &L, const float *v, const StartDesc
 // [starstart, starstop)) with c + e inside the grid: would serial_new/...:225-249 store?
 //   exactly one of T[c], T[o] infinite, or delay + T[o] < T[c], or delay + T[c] < T[o].
 
+template <bool EXACT>
 __global__ void __launch_bounds__(CELL_BX *CELL_BY)
 validate_kernel(DevLayout L, const float *__restrict__ v, const float *__restrict__ T,
                 long long sidx, const FwdEntry *__restrict__ entries, int nentries,
@@ -367,7 +387,7 @@ validate_kernel(DevLayout L, const float *__restrict__ v, const float *__restric
                 const long long oi = dev_index(L, oa, ob, oc);
                 const float to = T[oi];
                 const float sum = vc + v[oi];
-                const float delay = en.h * sum;
+                const float delay = edge_delay<EXACT>(en.h, sum);
                 const bool tinf = tc == __builtin_inff(), oinf = to == __builtin_inff();
                 if (tinf && oinf) continue;
                 if (tinf != oinf || delay + to < tc || delay + tc < to) open++;
@@ -391,6 +411,7 @@ validate_kernel(DevLayout L, const float *__restrict__ v, const float *__restric
 // counts[0] == 0 (no edge can still improve anything) this pins T to the one fixed point of
 // the relaxation, i.e. to the reference's converged result.  One thread per cell, the whole
 // pull star with the liveness rule of sweep_cell_kernel.
+template <bool EXACT>
 __global__ void __launch_bounds__(CELL_BX *CELL_BY)
 support_kernel(DevLayout L, const float *__restrict__ v, const float *__restrict__ T,
                long long sidx, const CellEntry *__restrict__ entries, int nentries,
@@ -414,7 +435,7 @@ support_kernel(DevLayout L, const float *__restrict__ v, const float *__restrict
                 // (ci is not the start, so PULL_FWD entries are live)
                 const bool live = (en.flags & PULL_FWD) || ((en.flags & PULL_REV) && oi != sidx);
                 const float sum = vc + v[oi];
-                const float delay = en.h * sum;
+                const float delay = edge_delay<EXACT>(en.h, sum);
                 const float cand = delay + T[oi];
                 if (live && cand < best) best = cand;
             }
@@ -428,17 +449,17 @@ support_kernel(DevLayout L, const float *__restrict__ v, const float *__restrict
 
 hipError_t launch_validate(const DevLayout &L, const float *v, const float *T, long long sidx,
                            const FwdEntry *entries, int nentries, const CellEntry *cell_entries,
-                           int ncell_entries, unsigned long long *counts, hipStream_t st)
+                           int ncell_entries, unsigned long long *counts, bool exact, hipStream_t st)
 {
     const int cblocks = (L.n[2] + CELL_BX - 1) / CELL_BX;
     const int bblocks = (L.n[1] + CELL_BY - 1) / CELL_BY;
     const long long nblocks = (long long)L.n[0] * bblocks * cblocks;
     if (nblocks <= 0) return hipSuccess;
     if (nblocks > 0x7fffffffLL) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(validate_kernel, dim3((unsigned)nblocks), dim3(CELL_BX, CELL_BY), 0, st, L, v,
-                       T, sidx, entries, nentries, counts, cblocks, bblocks);
-    hipLaunchKernelGGL(support_kernel, dim3((unsigned)nblocks), dim3(CELL_BX, CELL_BY), 0, st, L, v,
-                       T, sidx, cell_entries, ncell_entries, counts, cblocks, bblocks);
+    hipLaunchKernelGGL(exact ? validate_kernel<true> : validate_kernel<false>, dim3((unsigned)nblocks), dim3(CELL_BX, CELL_BY),
+                       0, st, L, v, T, sidx, entries, nentries, counts, cblocks, bblocks);
+    hipLaunchKernelGGL(exact ? support_kernel<true> : support_kernel<false>, dim3((unsigned)nblocks), dim3(CELL_BX, CELL_BY),
+                       0, st, L, v, T, sidx, cell_entries, ncell_entries, counts, cblocks, bblocks);
     return hipGetLastError();
 }
 
@@ -1530,6 +1551,7 @@ sweep_units_kernel(DevLayout L, const float *__restrict__ v, const StartDesc *__
 #ifdef TTSWEEP_ASYNC_STATS
     if (tid == 0) head[12] = 0;
 #endif
+    if (tid == 0) { head[13] = 0; head[14] = 0; }
     __syncthreads();
 
     if (ASYNC) {
@@ -1558,6 +1580,10 @@ sweep_units_kernel(DevLayout L, const float *__restrict__ v, const StartDesc *__
     // relaxed (`ahead`, held by thread 0); -1: nothing asked for yet.
     int ahead = -1;
     int flagged = -1;           // (lane 0 of a wave) the start whose "improved" bit this wave has set
+    // (thread 0) relaxations of the in-unit passes, summed until the workgroup turns to another start: the planner
+    // counts what it hands out, these it does not see
+    unsigned long long extra_relax = 0;
+    int extra_s = -1;
     const long long async_clock0 = ASYNC ? wall_clock64() : 0;
 #ifdef TTSWEEP_PROFILE
     unsigned long long prof_acc[7] = {};
@@ -1640,6 +1666,7 @@ sweep_units_kernel(DevLayout L, const float *__restrict__ v, const StartDesc *__
         // away.  Slab of staged plane p (plane a0 - ra + p): rows b0-rb .. b0+63+rb, columns
         // c0-CF .. c0+K+CF-1.
         unsigned todo = my_planes & plane_mask;
+        int improved_all = 0, inunit_passes = 0;
         const long long src0 = (long long)(a0 - plan.ra + L.lo[0]) * L.s0
                              + (long long)(b0 - rb + L.lo[1]) * L.s1 + (c0 - STRIP_CF + L.lo[2]);
         const unsigned s1_bytes = (unsigned)(L.s1 * 4);
@@ -1686,6 +1713,7 @@ sweep_units_kernel(DevLayout L, const float *__restrict__ v, const StartDesc *__
         }
 
         PROF_T(t_pro);
+        for (int iter = 0;; iter++) {
         while (todo) {
             const int p = __builtin_ctz(todo);
             todo &= todo - 1;
@@ -1790,6 +1818,46 @@ sweep_units_kernel(DevLayout L, const float *__restrict__ v, const StartDesc *__
         }
 #pragma unroll
         for (int w = 32; w >= 1; w >>= 1) improved |= __shfl_xor(improved, w);
+        improved_all |= improved;
+        // ---- one launch per solve, on request (AsyncSolve::inunit): while the unit improves, relax it again against
+        // its OWN planes - the values it has just stored -, up to `inunit` times: what crosses the unit's own cells
+        // (64 x 16 per plane, 7 cells a time) then needs no further turn of the unit through the planner and a ring
+        if (!ASYNC || iter >= as.inunit) break;
+        if (improved && lane == 0) atomicOr(&head[13 + (iter & 1)], 1);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        const int again = __builtin_amdgcn_readfirstlane(head[13 + (iter & 1)]);
+        if (tid == 0) head[13 + ((iter + 1) & 1)] = 0;
+        if (!again) break;
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");      // (the rows this CU staged before are stale in its L1)
+#pragma unroll
+        for (int qq = 0; qq < CQ; qq++) told[qq] = fminf(told[qq], best[qq]);
+        todo = (((1u << NP) - 1u) << plan.ra) & plane_mask;
+        inunit_passes++;
+        buf = 0;
+        if (todo) {
+            const long long src = src0 + (long long)__builtin_ctz(todo) * L.s0;
+            stage_slab(v + src, T + src, s1_bytes, slabs, rows, rows8, wave, lane);
+        }
+        cur = load_hdr(items, min(__builtin_amdgcn_readfirstlane(
+            item_range[wave * 16 + (todo ? __builtin_ctz(todo) : 0)]) & 0xffff, nitems - 1));
+        }
+        const int improved = improved_all;
+        const int a = a0 + fin_plane;
+        if (ASYNC && tid == 0) {
+            if (s != extra_s) {
+                if (extra_relax) atomicAdd(starts[extra_s].work, extra_relax);
+                extra_relax = 0;
+                extra_s = s;
+            }
+            // (iter: the passes that followed the first one)
+            const int wb = min(tb_eff, L.n[1] - b0), wc = max(min(K, L.n[2] - c0), 0);
+            const bool two = NP > 1 && a0 + 1 < L.n[0];
+            int nent = 0;
+#pragma unroll
+            for (int j = 0; j < NP; j++) nent += pc.n[plan.ra + j][0] + (two ? pc.n[plan.ra + j][1] : 0);
+            extra_relax += (unsigned long long)inunit_passes * (unsigned long long)(wb * wc) * (unsigned long long)nent;
+        }
 #ifdef TTSWEEP_ASYNC_STATS
         if (ASYNC && improved && lane == 0) atomicOr(&head[12], 1);      // (tuning aid: did this unit improve anything?)
 #endif
@@ -1845,7 +1913,10 @@ sweep_units_kernel(DevLayout L, const float *__restrict__ v, const StartDesc *__
     }
 #endif
 
-    if (ASYNC) return;          // (the host reads the words after the one launch)
+    if (ASYNC) {                // (the host reads the words after the one launch)
+        if (tid == 0 && extra_relax) atomicAdd(starts[extra_s].work, extra_relax);
+        return;
+    }
     // ---- the last workgroup to leave closes the pass: it hands the "changed" words to the
     // host (pinned memory) and clears the queue counters and the next pass's words, so a pass
     // needs no memset / copy commands around its two kernels.  All its threads take part (one
