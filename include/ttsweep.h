@@ -119,7 +119,7 @@ typedef struct ttsweep_ctx ttsweep_ctx;
                                          reported at once only to the units that are not nearer to the start
                                          than the improved cells by more than this many cells (x 1/1000, may be
                                          negative); the units behind the front hear of it when the start is
-                                         otherwise at rest, once, instead of in every pass.  Default 1000 (one cell);
+                                         otherwise at rest, once, instead of in every pass.  Default 500 (half a cell);
                                          <= -1000000000 switches the deferral off */
 #define TTSWEEP_OPT_ASYNC_WINDOW_MILLI 15 /* schedule only: ring policy 2 - cells (x 1/1000) beyond the nearest unit
                                          with anything to do up to which a start's units are handed out; 0 = no

@@ -831,6 +831,10 @@ SCHEDULES = [
     (1, {"OPT_DEFER_MARGIN_MILLI": -4000}),
     (1, {"OPT_DEFER_MARGIN_MILLI": 0, "OPT_GATE_SPEED_MILLI": 0}),
     (1, {"OPT_DEFER_MARGIN_MILLI": 6000, "OPT_PAIR_MIN_STARTS": 0}),
+    (1, {"OPT_ASYNC_INUNIT": 0}),
+    (1, {"OPT_ASYNC_INUNIT": 1, "OPT_PAIR_MIN_STARTS": 0}),
+    (1, {"OPT_ASYNC_INUNIT": 8, "OPT_DEFER_MARGIN_MILLI": 1000}),
+    (1, {"OPT_ASYNC_INUNIT": 3, "OPT_PAIR_MIN_STARTS": 0, "OPT_ASYNC_POLICY": 0}),
     (0, {"OPT_DEFER_MARGIN_MILLI": -1000000000}),
     (0, {"OPT_DEFER_MARGIN_MILLI": -4000}),
     (0, {"OPT_DEFER_MARGIN_MILLI": 0, "OPT_PAIR_MIN_STARTS": 0}),
@@ -842,7 +846,8 @@ SCHEDULES = [
                                                            for a, o in SCHEDULES])
 def test_result_does_not_depend_on_the_schedule(P, golden24, one_launch, options):
     """The STRIP kernel's schedule - a solve as one launch (ring policies, fill marks, gate per round, window,
-    how often the dead-edge cells are relaxed) or as a launch pair per pass, and the deferral of the
+    how often the dead-edge cells are relaxed, how often a unit that improved is relaxed again against its own
+    planes before it is handed back) or as a launch pair per pass, and the deferral of the
     bits for units behind the front (off, eager, far too eager: the late relaxations then improve cells and
     the solve goes on) - never changes a bit of the converged boxes: 818-FS, interior, corner and dead-edge
     starts in one batch, against the reference's boxes."""

@@ -1,5 +1,5 @@
 """Knob sweep of the one-launch STRIP solve on the headline grid.
-usage: async_sweep.py nstarts cfg [cfg ...]   cfg = async:pair:low:high:special:policy:gate_milli:margin_milli[:fast_gate_milli]  (pair -1 = default rule, gate -1 = default, margin -1000000000 = off)"""
+usage: async_sweep.py nstarts cfg [cfg ...]   cfg = async:pair:low:high:special:policy:gate_milli:margin_milli[:fast_gate_milli[:in-unit passes]]  (pair -1 = default rule, gate -1 = default, margin -1000000000 = off)"""
 import os, sys, json, hashlib, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch, ttsweep_pkg
@@ -34,6 +34,7 @@ for cfg in sys.argv[2:]:
         if gate >= 0: sol.set_option(P.OPT_ASYNC_WINDOW_MILLI if policy == 2 else (P.OPT_ASYNC_GATE_MILLI if mode == 1 else P.OPT_GATE_SPEED_MILLI), gate)
         sol.set_option(P.OPT_DEFER_MARGIN_MILLI, margin)
         if fast >= 0: sol.set_option(P.OPT_ASYNC_GATE_FAST_MILLI, fast)
+        if len(f) > 9: sol.set_option(P.OPT_ASYNC_INUNIT, f[9])
         best = None
         for rep in range(3):
             rc = sol.solve_device(starts, tt, init=True)

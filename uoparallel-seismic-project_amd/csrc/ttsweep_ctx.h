@@ -100,7 +100,7 @@ struct ttsweep_ctx {
     double gate_r0 = 0.0;
     // STRIP: bits for units nearer to the start than the improved cells by more than this many cells are
     // deferred until the start is otherwise at rest (push_improved); < -1e30: off
-    float defer_margin = 1.f;
+    float defer_margin = 0.5f;                  // (cells; measured with the in-unit passes: 24 starts 29.3 -> 28.6 ms, 3 starts 7.77 -> 7.35: profiles/r04_schedule_knobs.txt)
     bool defer_suspended = false;           // (pass driver) the solve in progress has flushed once: no more deferral
     // STRIP, one launch per solve (AsyncSolve, ttsweep_dev.h)
     int async_mode = -1;                    // TTSWEEP_OPT_ASYNC
