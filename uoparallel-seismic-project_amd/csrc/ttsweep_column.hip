@@ -46,13 +46,33 @@ typedef __attribute__((address_space(3))) char *lds_char;
 constexpr int CS = 16;                          // cells of a chunk along z
 constexpr int CRING = 3;                        // chunks of a row the ring holds
 constexpr int CNR = (TILE_X + 2) * (TILE_Y + 2) - 2;   // image rows: 10 x 10 but the first and the last (98)
-constexpr int CROWB = CS * 4;                   // bytes of a row of a chunk
-constexpr int CSLOTB = CNR * CROWB;             // bytes of a chunk (one array)
-constexpr int CARRB = 18944;                    // the ring of one array (>= CRING * CSLOTB, whole 256-byte blocks)
+// A chunk in LDS: the float4s of an image row (cells 4 q .. 4 q + 3) come in groups of CG; group q / CG of row r
+// lives in the 16-byte slots (q / CG) CKQ CG + r CG + q % CG.  CG = 4: plain rows of 64 bytes (the default).
+// Neighbouring rows are a constant 16 CG (y) / 160 CG (x) bytes apart whatever the cell - one address table serves a
+// lane and its four lateral neighbours.  With plain rows every LDS access of a step is a 2-way bank conflict (a
+// 32-lane group falls on 16 banks: SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE 0.49); CG = 2 with CKQ = 100 and CG = 1
+// with CKQ = 104 (padding rows per plane) put the 32 lanes of EVERY access - own row or a neighbour's, any step of
+// the ring period, either z direction - on 32 different banks (measured: the conflict counter reads 0).  But the
+// LDS-DMA places lane l of an instruction at byte 16 l of its block, so consecutive lanes fetch consecutive bytes of
+// the volume only within a group: an instruction touches 16 / 32 / 64 cache lines for CG = 4 / 2 / 1, and the solve
+// of 1024x1024x512 x 14 takes 115.5 / 129.4 / 155.7 ms (profiles/r04_lds_layouts.txt): the staging path, not the
+// LDS array, is what the conflict-free images load; the conflicts themselves cost nothing measurable (the LDS array
+// is 33 % busy with them).
+#ifndef TTSWEEP_COL_CG
+#define TTSWEEP_COL_CG 4
+#endif
+constexpr int CG = TTSWEEP_COL_CG;              // float4s of a row that stay together
+constexpr int CKQ = CG == 1 ? 104 : CG == 2 ? 100 : CNR;       // rows of a plane (>= CNR)
+constexpr int CROWB = 16 * CG;                  // bytes from an image row to the next
+constexpr int CPLANEB = CKQ * CROWB;            // bytes of a plane
+constexpr int CSLOTB = (CS / 4 / CG) * CPLANEB; // bytes of a chunk (one array)
+constexpr int CARRB = (CRING * CSLOTB + 255) / 256 * 256;      // the ring of one array (whole 256-byte blocks)
 constexpr int CLDSB = 2 * CARRB;                // v ring, T ring
 constexpr int CDX = (TILE_Y + 2) * CROWB;       // from an image row to its x + 1 neighbour
 constexpr int CPER = CS * CRING;                // steps of the ring period
-constexpr int CNDMA = (CNR * (CS / 4) + 63) / 64;      // LDS-DMA wave instructions per chunk and array (7)
+constexpr int CNSLOT = CSLOTB / 16;             // 16-byte slots of a chunk
+constexpr int CNDMA = (CNSLOT + 63) / 64;       // LDS-DMA wave instructions per chunk and array (7)
+constexpr int CTAIL = CNSLOT % 64 ? CNSLOT % 64 : 64;  // lanes of the last one
 constexpr int CSIG = TILE_X + TILE_Y - 2;       // largest lane skew (14)
 // wavefronts of a workgroup: each works on its own column with its own rings, they never meet (no barrier); they are
 // ONE workgroup so that the CU places them on its four SIMDs, one each (single-wavefront workgroups land wherever the
@@ -63,7 +83,12 @@ constexpr int CSIG = TILE_X + TILE_Y - 2;       // largest lane skew (14)
 constexpr int CWG = TTSWEEP_COL_WG_WAVES;
 static_assert(CWG >= 1 && CWG <= COL_WAVES, "a workgroup's rings must fit the CU's LDS");
 static_assert(TILE_X == 8 && TILE_Y == 8 && TILE_Z == 2 * CS, "column pipelines: 8 x 8 x 32 tiles");
-static_assert(CARRB >= CRING * CSLOTB && CARRB % 256 == 0, "ring size");
+static_assert((CG == 1 || CG == 2 || CG == 4) && CKQ >= CNR && COL_WAVES * CLDSB <= 160 * 1024, "ring size");
+// byte offset of cell z (0 .. CS - 1) of image row r in its chunk
+__host__ __device__ constexpr int col_cell_off(int r, int z) { return ((z >> 2) / CG) * CPLANEB + r * CROWB + ((z >> 2) % CG) * 16 + (z & 3) * 4; }
+// 16-byte slot `slot` of a chunk: its image row (the padding rows of a plane stand for its last row) and float4
+__host__ __device__ constexpr int col_slot_row(int slot) { return (slot % (CKQ * CG)) / CG < CNR ? (slot % (CKQ * CG)) / CG : CNR - 1; }
+__host__ __device__ constexpr int col_slot_quad(int slot) { return (slot / (CKQ * CG) < CS / 4 / CG ? slot / (CKQ * CG) : CS / 4 / CG - 1) * CG + slot % CG; }
 
 __device__ __forceinline__ col_rsrc col_make_rsrc(const float *base)
 {
@@ -192,7 +217,7 @@ __device__ __forceinline__ void col_stage(const lds_char lp, const float *vsrc, 
     const col_rsrc rv = col_make_rsrc(vsrc), rt = col_make_rsrc(tsrc);
 #pragma unroll
     for (int q = 0; q < CNDMA; q++) {
-        if (q < CNDMA - 1 || lane < (CNR * (CS / 4)) % 64) {
+        if (q < CNDMA - 1 || lane < CTAIL) {
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rv, (__attribute__((address_space(3))) void *)(lp + SLOT * CSLOTB + q * 1024),
                                                      16, (int)goffv[q], 0, 0, 0);
             if (!RIM || zin) {
@@ -224,7 +249,7 @@ __device__ __forceinline__ void col_fill_rows(const lds_char lp, const int lane,
     for (int slot = 0; slot < CRING; slot++)
 #pragma unroll
         for (int q = 0; q < CNDMA; q++)
-            if ((q < CNDMA - 1 || lane < (CNR * (CS / 4)) % 64) && !((tvalid >> q) & 1u))
+            if ((q < CNDMA - 1 || lane < CTAIL) && !((tvalid >> q) & 1u))
                 *reinterpret_cast<__attribute__((address_space(3))) col_f4 *>(lp + CARRB + slot * CSLOTB + q * 1024 + lane * 16) =
                     col_f4{inf, inf, inf, inf};
 }
@@ -393,7 +418,8 @@ column_solve_kernel(const ColumnSolve P)
     unsigned goffv[CNDMA], gofft[CNDMA];
 #pragma unroll
     for (int q = 0; q < CNDMA; q++) {
-        const int sidx = 64 * q + lane, r = sidx >> 2, quad = sidx & 3;
+        // (the padding slots of a float4 plane fetch its last row once more: nobody reads them)
+        const int sidx = 64 * q + lane, quad = col_slot_quad(sidx), r = col_slot_row(sidx);
         const int ri = (r + 1) / (TILE_Y + 2), rj = (r + 1) % (TILE_Y + 2);        // padded image coordinates 0 .. 9
         goffv[q] = (unsigned)(((long long)ri * L.s0 + (long long)rj * L.s1) * 4 + quad * 16);
         gofft[q] = (unsigned)(((long long)ri * P.ts0 + (long long)rj * P.ts1) * 4 + quad * 16);
@@ -404,7 +430,7 @@ column_solve_kernel(const ColumnSolve P)
     for (int k = 0; k < 4; k++) {
         const int sidx = 64 * k + lane, ir = sidx >> 2, quad = sidx & 3, ci = ir >> 3, cj = ir & 7;
         wbg[k] = (unsigned)(((long long)(ci + 1) * P.ts0 + (long long)(cj + 1) * P.ts1) * 4 + quad * 16);
-        wbl[k] = CARRB + ((ci + 1) * (TILE_Y + 2) + cj) * CROWB + quad * 16;
+        wbl[k] = CARRB + col_cell_off((ci + 1) * (TILE_Y + 2) + cj, 4 * quad);
     }
 
     const int seq = cuni((int)blockIdx.x % P.nseq);
@@ -453,7 +479,8 @@ column_solve_kernel(const ColumnSolve P)
             for (int n = 0; n < CPER; n++) {
                 const int wq = n - sig + (n < sig ? CPER : 0);
                 const int slot = wq >> 4, zc = wq & (CS - 1);
-                AX[n] = lbase + slot * CSLOTB + rxm * CROWB + (sz > 0 ? zc : CS - 1 - zc) * 4;
+                const int z = sz > 0 ? zc : CS - 1 - zc;
+                AX[n] = lbase + slot * CSLOTB + col_cell_off(rxm, z);
             }
         }
         ColConst cc;
@@ -512,7 +539,7 @@ column_solve_kernel(const ColumnSolve P)
             tvalid = 0u;
 #pragma unroll
             for (int q = 0; q < CNDMA; q++) {
-                const int r = (64 * q + lane) >> 2;
+                const int r = col_slot_row(64 * q + lane);
                 const int x = I * TILE_X + (r + 1) / (TILE_Y + 2) - 1, y = J * TILE_Y + (r + 1) % (TILE_Y + 2) - 1;
                 if ((unsigned)x < (unsigned)L.n[0] && (unsigned)y < (unsigned)L.n[1]) tvalid |= 1u << q;
             }
