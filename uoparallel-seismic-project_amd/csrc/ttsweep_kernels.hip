@@ -1370,8 +1370,12 @@ __device__ __forceinline__ void async_planner(const DevLayout &L, const StartDes
                 if (w[k] != 0u) {
                     activity = 1;
                     if (as.policy == 2) atomicMin(&minact[ss[k] >> 16], dd[k]);
-                    // only the planner sets the busy bit: a word seen without it holds plane bits alone
-                    if (!(w[k] & ASYNC_BUSY)) planes[k] = atomicExch(pw[k], ASYNC_BUSY) & ~ASYNC_BUSY;
+                    // only the planner sets the busy bit: a word seen without it holds plane bits alone.
+                    // (minbits: while the ring still holds entries nobody has claimed, a unit with fewer changed
+                    // planes than that is left to collect more - it is relaxed once against several instead of
+                    // several times against one or two)
+                    if (!(w[k] & ASYNC_BUSY) && (__builtin_popcount(w[k]) >= as.minbits || (int)(t - h) <= 0))
+                        planes[k] = atomicExch(pw[k], ASYNC_BUSY) & ~ASYNC_BUSY;
                 }
             }
             int rank[KSCAN];
