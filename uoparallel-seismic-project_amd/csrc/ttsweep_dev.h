@@ -187,7 +187,6 @@ struct AsyncSolve {
     float gate_fast;                // policy 1: cells per round while the ring is empty at the beginning of a round
     float window;                   // policy 2; <= 0: no gate
     int scan_slack;                 // list entries in front of the first unit with anything to do that a round still scans
-    int minbits;                    // changed planes a unit needs to be handed out while the ring is not empty
     int inunit;                     // times a unit that improved is relaxed again against its own planes before it is handed back
     int ring_off[ASYNC_MAX_RINGS], ring_len[ASYNC_MAX_RINGS];
     int ring_start_off[ASYNC_MAX_RINGS + 1];    // ring r serves starts ring_starts[ring_start_off[r] .. [r + 1])

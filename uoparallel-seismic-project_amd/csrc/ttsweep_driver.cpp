@@ -265,7 +265,6 @@ static int solve_async_strip(ttsweep_ctx *ctx, int nstart, std::vector<int> &swe
     // a unit that improved is relaxed again against its own planes, at once (measured: 24 starts 34.5 -> 29.4 ms with
     // two such passes - the planner hands out a third less -, 3 starts 7.85 -> 7.77, one start 6.38 -> 6.52:
     // profiles/r04_inunit.txt)
-    as.minbits = getenv("TTSWEEP_MINBITS") ? atoi(getenv("TTSWEEP_MINBITS")) : 1;
     as.inunit = ctx->async_inunit >= 0 ? ctx->async_inunit : (nstart >= 2 ? 2 : 0);
     if (!cached && flat.size() > ctx->async_list_cap) {
         if (ctx->d_async_list) HIPCHK(hipFree(ctx->d_async_list));

@@ -1370,12 +1370,8 @@ __device__ __forceinline__ void async_planner(const DevLayout &L, const StartDes
                 if (w[k] != 0u) {
                     activity = 1;
                     if (as.policy == 2) atomicMin(&minact[ss[k] >> 16], dd[k]);
-                    // only the planner sets the busy bit: a word seen without it holds plane bits alone.
-                    // (minbits: while the ring still holds entries nobody has claimed, a unit with fewer changed
-                    // planes than that is left to collect more - it is relaxed once against several instead of
-                    // several times against one or two)
-                    if (!(w[k] & ASYNC_BUSY) && (__builtin_popcount(w[k]) >= as.minbits || (int)(t - h) <= 0))
-                        planes[k] = atomicExch(pw[k], ASYNC_BUSY) & ~ASYNC_BUSY;
+                    // only the planner sets the busy bit: a word seen without it holds plane bits alone
+                    if (!(w[k] & ASYNC_BUSY)) planes[k] = atomicExch(pw[k], ASYNC_BUSY) & ~ASYNC_BUSY;
                 }
             }
             int rank[KSCAN];
@@ -1778,8 +1774,6 @@ sweep_units_kernel(DevLayout L, const float *__restrict__ v, const StartDesc *__
             p_comp += clock64() - t2;
 #endif
         }
-        PROF_T(t_loop);
-
         // ---- min-combine the waves' partial results; wave w finishes cells fin_q0 .. + CQ - 1
         // of own plane fin_plane
         __syncthreads();                // the last slab is no longer read
@@ -1846,6 +1840,7 @@ sweep_units_kernel(DevLayout L, const float *__restrict__ v, const StartDesc *__
         cur = load_hdr(items, min(__builtin_amdgcn_readfirstlane(
             item_range[wave * 16 + (todo ? __builtin_ctz(todo) : 0)]) & 0xffff, nitems - 1));
         }
+        PROF_T(t_loop);         // (the in-unit passes count as compute: -DTTSWEEP_PROFILE)
         const int improved = improved_all;
         const int a = a0 + fin_plane;
         if (ASYNC && tid == 0) {
@@ -1905,7 +1900,7 @@ sweep_units_kernel(DevLayout L, const float *__restrict__ v, const StartDesc *__
             prof_acc[2] += (unsigned long long)p_wait;
             prof_acc[3] += (unsigned long long)p_stage;
             prof_acc[4] += (unsigned long long)p_comp;
-            prof_acc[5] += (unsigned long long)(t_end - t_loop);
+            prof_acc[5] += (unsigned long long)(t_end - t_loop);      // (push, completion)
             prof_acc[6] += 1ull;
         }
 #endif
