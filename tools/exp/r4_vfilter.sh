@@ -1,0 +1,9 @@
+#!/bin/bash
+cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+O=gpurun_out/r4_vfilter.txt; : > $O
+for n in 24 8 3 1; do
+for f in 0 1; do
+echo "== $n starts, value filter $f" >> $O
+TTSWEEP_VALUE_FILTER=$f python tools/exp/async_sweep.py $n 1:-1:0:0:0:1:-1:500 1:-1:0:0:0:1:-1:-1000000000 1:-1:0:0:0:1:-1:2000 2>&1 | grep solve >> $O
+done; done
+cat $O
