@@ -119,13 +119,13 @@ typedef struct ttsweep_ctx ttsweep_ctx;
                                          reported at once only to the units that are not nearer to the start
                                          than the improved cells by more than this many cells (x 1/1000, may be
                                          negative); the units behind the front hear of it when the start is
-                                         otherwise at rest, once, instead of in every pass.  Default 500 (half a cell);
+                                         otherwise at rest, once, instead of in every pass.  Default 375 (3/8 of a cell);
                                          <= -1000000000 switches the deferral off */
 #define TTSWEEP_OPT_ASYNC_WINDOW_MILLI 15 /* schedule only: ring policy 2 - cells (x 1/1000) beyond the nearest unit
                                          with anything to do up to which a start's units are handed out; 0 = no
                                          gate */
 #define TTSWEEP_OPT_ASYNC_GATE_MILLI 16 /* schedule only: ring policy 1 - cells (x 1/1000) by which the distance gate
-                                         opens per round of a one-launch solve (default 750; 0 = no gate;
+                                         opens per round of a one-launch solve (default 500; 0 = no gate;
                                          TTSWEEP_OPT_GATE_SPEED_MILLI = 0 switches this gate off as well) */
 #define TTSWEEP_OPT_ASYNC_GATE_FAST_MILLI 17 /* schedule only: ring policy 1 - cells (x 1/1000) by which the gate opens
                                          in a round that begins with an empty ring (the workers are running dry);

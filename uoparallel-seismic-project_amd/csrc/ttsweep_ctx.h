@@ -100,7 +100,7 @@ struct ttsweep_ctx {
     double gate_r0 = 0.0;
     // STRIP: bits for units nearer to the start than the improved cells by more than this many cells are
     // deferred until the start is otherwise at rest (push_improved); < -1e30: off
-    float defer_margin = 0.5f;                  // (cells; measured with the in-unit passes: 24 starts 29.3 -> 28.6 ms, 3 starts 7.77 -> 7.35: profiles/r04_schedule_knobs.txt)
+    float defer_margin = 0.375f;                // (cells; measured with the in-unit passes, profiles/r04_schedule_knobs.txt)
     bool defer_suspended = false;           // (pass driver) the solve in progress has flushed once: no more deferral
     // STRIP, one launch per solve (AsyncSolve, ttsweep_dev.h)
     int async_mode = -1;                    // TTSWEEP_OPT_ASYNC
@@ -108,7 +108,7 @@ struct ttsweep_ctx {
     int async_special_every = 128;
     int async_timeout_ms = 0;               // TTSWEEP_OPT_ASYNC_TIMEOUT_MILLI (0: from the size of the solve)
     int async_policy = 1;                   // TTSWEEP_OPT_ASYNC_POLICY
-    float async_gate_speed = 0.75f;         // cells per round (policy 1; TTSWEEP_OPT_ASYNC_GATE_MILLI)
+    float async_gate_speed = 0.5f;          // cells per round (policy 1; TTSWEEP_OPT_ASYNC_GATE_MILLI)
     float async_gate_fast = 2.0f;           // ... while the workers are running dry (TTSWEEP_OPT_ASYNC_GATE_FAST_MILLI)
     float async_window = 16.f;              // TTSWEEP_OPT_ASYNC_WINDOW_MILLI
     int4 *d_async_list = nullptr;           // the rings' unit lists
