@@ -31,7 +31,8 @@ with P.TravelTimeSolver(v.shape, fs) as sol:
             sol.set_option(P.OPT_ASYNC_GATE_MILLI, int(rng.integers(300, 4000)))
             sol.set_option(P.OPT_ASYNC_GATE_FAST_MILLI, int(rng.integers(300, 6000)))
             sol.set_option(P.OPT_ASYNC_SPECIAL, int(rng.integers(1, 1000)))
-            sol.set_option(P.OPT_DEFER_MARGIN_MILLI, int(rng.integers(500, 4000)))
+            sol.set_option(P.OPT_DEFER_MARGIN_MILLI, int(rng.integers(-500, 4000)))
+            sol.set_option(P.OPT_ASYNC_INUNIT, int(rng.integers(-1, 5)))
             sol.set_option(P.OPT_PAIR_MIN_STARTS, int(rng.choice([0, 1 << 20])))
         nst = int(rng.integers(1, len(starts) + 1)) if it else len(starts)
         rc = sol.solve_device(starts[:nst], tt[:nst], init=True)
