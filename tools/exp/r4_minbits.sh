@@ -1,4 +1,5 @@
 #!/bin/bash
+# (experiment of round 4; the code it switched on was measured, recorded under profiles/ and REMOVED: see HISTORY.md)
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 O=gpurun_out/r4_minbits.txt; : > $O
 for n in 24 8 3; do

@@ -1,4 +1,5 @@
 #!/bin/bash
+# (experiment of round 4; the code it switched on was measured, recorded under profiles/ and REMOVED: see HISTORY.md)
 # split units (TTSWEEP_SPLIT, experiment): a unit's changed planes dealt over 1 .. 4 ring entries
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 O=gpurun_out/r4_split.txt; : > $O
