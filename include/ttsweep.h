@@ -34,7 +34,8 @@
 extern "C" {
 #endif
 
-#define TTSWEEP_ABI_VERSION 4
+#define TTSWEEP_ABI_VERSION 5      /* 5 (round 4): + ttsweep_get_changed, ttsweep_solve_multi_device, stats.fallbacks (in the struct's former
+                                      padding), options 19-21; every version-4 caller runs unchanged */
 
 /* Forward-star entry: same layout as `struct FS`
  * (serial_new/sweep-tt-multistart.c:46-49).  d must already hold
