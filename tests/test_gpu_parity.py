@@ -964,6 +964,30 @@ def test_starts_per_ring_limit_with_few_queues(P, queues, nstart, one_launch):
             sol.set_option(P.OPT_QUEUES, 9)
 
 
+@pytest.mark.parametrize("queues", [1, 3, 8])
+def test_column_driver_with_fewer_claim_sequences(P, oracle, queues):
+    """The column driver deals the tile positions over one claim sequence per XCD; a partition shows fewer XCDs
+    (TTSWEEP_OPT_QUEUES forces the count): one, three and eight sequences, the same fixed point, bit for bit."""
+    import torch
+    shape = (70, 33, 96)
+    rng = np.random.default_rng(61)
+    v = rng.uniform(0.1, 0.5, size=shape).astype(np.float32)
+    six = P.inputs.read_triples(P.inputs.star_path("six"))
+    fs = P.inputs.make_fs(six)
+    starts = np.array([[5, 30, 90], [69, 0, 0]], dtype=np.int32)
+    want = [oracle.converge(v, oracle.make_star(six), st, order=1)[0] for st in starts]
+    with P.TravelTimeSolver(shape, fs) as sol:
+        sol.set_option(P.OPT_KERNEL, 3)
+        sol.set_option(P.OPT_QUEUES, queues)
+        sol.set_velocity(v)
+        tt = torch.empty((2,) + shape, dtype=torch.float32, device=torch.device("cuda:0"))
+        assert sol.solve_device(starts, tt, init=True) == 1
+        st = sol.stats()
+        assert st["kernel_variant"] == 3 and st["launches"] == 1 and st["fallbacks"] == 0
+        for s in range(2):
+            assert_bit_equal(tt[s].cpu().numpy(), want[s], f"{queues} sequences, start {starts[s]}")
+
+
 def test_column_rest_is_declared_once_per_start(P):
     """Three starts that come to rest in different sweeps, many times over: successive sweeps of the column driver
     overlap, and two of them can both end without an improvement before either hears of the other - the start
