@@ -113,6 +113,50 @@ def cpu_baseline_cores(shape, star, starts_name, ncores, sweeps=1):
                       f"{len(os.sched_getaffinity(0))} in the affinity mask, {usable_cores()} within the CPU quota)"}
 
 
+def cpu_leg_b2(P):
+    """BASELINE.md section 3, leg B2: start-1 of the 241x241x51 workload relaxed to convergence in the reference's
+    order (sweep body serial_new/sweep-tt-multistart.c:198-256, driver loop old/sweep-serial/...:189-211) with the CPU
+    restatement on ONE host core; the box's SHA-256 against the one recorded from the unmodified reference."""
+    import hashlib
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import oracle as O
+    O.build()
+    v = P.inputs.velocity_model(241, 241, 51, 20160507)
+    fs = O.make_star(P.inputs.read_triples(P.inputs.star_path("818")))
+    start = P.inputs.read_triples(P.inputs.starts_path("1"))[0]
+    t0 = time.perf_counter()
+    tt, sweeps, stores = O.converge(v, fs, start, order=0)
+    dt = time.perf_counter() - t0
+    sha = hashlib.sha256(tt.tobytes()).hexdigest()
+    want = None
+    try:
+        d = json.load(open(os.path.join(ROOT, "tests", "golden", "big_digests.json")))
+        want = d["syn241_818_%d_%d_%d" % tuple(int(x) for x in start)]["sha256"]
+    except Exception:
+        pass
+    return {"leg": "B2", "grid": [241, 241, 51], "star": "818-FS", "start": [int(x) for x in start], "cores": 1, "kind": "port",
+            "sweeps_incl_confirming": int(sweeps), "stores": int(stores), "seconds": round(dt, 2),
+            "seconds_per_sweep": dt / max(int(sweeps), 1), "value": v.size * int(sweeps) / dt / 1e6, "unit": "Mcells*sweeps/s",
+            "sha256": sha, "matches_reference_digest": (sha == want) if want else None,
+            "sample": "start-1 to convergence, reference order, single thread, gcc -O3 (measured in this run)"}
+
+
+def gather_report(gather, ranks_info, shards, cells):
+    """config.gather of the line: where the boxes went and why (multistart.plan_gather) and, for N > 1, what the
+    timed steps saw - bytes that crossed to the root per step and the rate over the slowest rank's gather time (the
+    root waits for all senders).  Everything here is MEASURED; nothing is quoted from another run."""
+    out = dict(gather)
+    if ranks_info:
+        moved = sum(len(sh) for r, sh in enumerate(shards) if r != 0) * cells * 4
+        slowest = max(r["gather_ms"] for r in ranks_info)
+        out["bytes_to_root_per_step"] = int(moved)
+        out["slowest_rank_gather_ms"] = slowest
+        out["achieved_GBps"] = moved / (slowest / 1e3) / 1e9 if slowest > 0 else None
+        out["note"] = ("gather_ms per rank = wall time from the end of its solve to the completion of its part of the "
+                       "gather, so a rank that finishes its shard early also waits there for the slowest solver")
+    return out
+
+
 def reference_sweep_counts(star, starts):
     """Sweeps the unmodified reference needed per start (recorded with the reference itself,
     tests/golden/big_digests.json), for the starts that were recorded."""
@@ -339,6 +383,11 @@ def main():
                     help="schedule knob of the STRIP kernel: 1 one launch per solve, 0 a launch pair per pass, -1 library default")
     ap.add_argument("--async-gate", type=float, default=None, help="schedule knob: cells per round by which the gate of a one-launch solve opens")
     ap.add_argument("--inunit", type=int, default=None, help="schedule knob: passes of a unit that improved against its own planes (one-launch STRIP solve)")
+    ap.add_argument("--handoff", type=int, default=None, help="schedule knob: TTSWEEP_OPT_ASYNC_HANDOFF (workers publish successor units themselves)")
+    ap.add_argument("--waves", type=int, default=None, choices=[-1, 4, 8], help="schedule knob: TTSWEEP_OPT_ASYNC_WAVES (waves that relax a unit)")
+    ap.add_argument("--cpu-b2", action="store_true",
+                    help="BASELINE.md leg B2 in this run: start-1 relaxed to convergence in the reference's order on ONE host "
+                         "core with the CPU restatement (about 190 s; not part of the driver's default run)")
     ap.add_argument("--defer-margin", type=float, default=None,
                     help="schedule knob: improvements are told at once only to units not nearer to the start by more than this (cells)")
     ap.add_argument("--prepass", type=int, default=0,
@@ -403,26 +452,36 @@ def main():
     dev_index = local_rank % max(ndev, 1)
     dev = torch.device("cuda", dev_index)
     torch.cuda.set_device(dev)
-    ctl = None                  # gloo group for everything that is not the gather: barriers, plans, the max-over-ranks clock
+    # Process groups.  The DEFAULT group is gloo - barriers, plans, the max-over-ranks clock, the diagnostics - and
+    # comes up first.  RCCL (backend "nccl" IS RCCL on ROCm) is a group of its own for the gather alone, and the ranks
+    # AGREE on whether it works before anybody depends on it: every rank tries the group and one tiny all-reduce on
+    # its device, the outcomes are min-reduced over gloo, and unless every rank succeeded all of them go on under gloo
+    # with the host gather (and the line says why).  A rank that fails alone therefore cannot leave the others inside
+    # an RCCL rendezvous (round 4 decided per rank).
+    rccl = None
     rccl_note = None
     if world > 1:
+        import datetime
         import torch.distributed as dist
+        dist.init_process_group("gloo")
         if args.backend == "nccl":
-            # One rank per GPU over RCCL (backend "nccl" IS RCCL on ROCm).  First contact with RCCL must not cost the
-            # line: if the communicator cannot be set up the run goes on under gloo (host gather) and says so.
+            err = None
             try:
-                dist.init_process_group("nccl", device_id=dev)
+                rccl = dist.new_group(backend="nccl", timeout=datetime.timedelta(seconds=180))
+                probe = torch.ones(1, device=dev)
+                dist.all_reduce(probe, group=rccl)
+                torch.cuda.synchronize()
+                if int(probe.item()) != world:
+                    err = f"RCCL probe all-reduce returned {probe.item()} for {world} ranks"
             except Exception as e:      # noqa: BLE001 - whatever RCCL / the rendezvous raises
-                rccl_note = f"init_process_group('nccl') failed: {type(e).__name__}: {e}"[:300]
-                try:
-                    dist.destroy_process_group()
-                except Exception:       # noqa: BLE001
-                    pass
+                err = f"rank {rank}: RCCL group / probe failed: {type(e).__name__}: {e}"[:300]
+            errs = [None] * world
+            dist.all_gather_object(errs, err)
+            bad = [x for x in errs if x]
+            if bad:
+                rccl_note = bad[0] if len(bad) == world else f"{len(bad)} of {world} ranks: {bad[0]}"[:300]
+                rccl = None
                 args.backend = "gloo"
-                dist.init_process_group("gloo")
-        else:
-            dist.init_process_group(args.backend)
-        ctl = dist.new_group(backend="gloo") if args.backend == "nccl" else None
 
     if small:
         v_dev = torch.from_numpy(v_host).to(dev)
@@ -448,6 +507,10 @@ def main():
         sol.set_option(P.OPT_DEFER_MARGIN_MILLI, int(round(args.defer_margin * 1000)))
     if args.inunit is not None:
         sol.set_option(P.OPT_ASYNC_INUNIT, args.inunit)
+    if args.handoff is not None:
+        sol.set_option(P.OPT_ASYNC_HANDOFF, args.handoff)
+    if args.waves is not None:
+        sol.set_option(P.OPT_ASYNC_WAVES, args.waves)
     sol.set_velocity(v_dev)
     if args.prepass:
         sol.set_option(P.OPT_PREPASS_ENTRIES, args.prepass)
@@ -465,18 +528,33 @@ def main():
             plan[0] = P.multistart.plan_gather(nstart, cells * 4, free_dev)
             if args.gather != "auto":
                 plan[0] = {"path": args.gather, "bytes": nstart * cells * 4, "why": "--gather"}
-        dist.broadcast_object_list(plan, src=0, group=ctl)
+        dist.broadcast_object_list(plan, src=0)
         gather = plan[0]
         if rccl_note:
             gather = dict(gather, path="host", why=rccl_note)
 
-    def step():
-        sol.solve_device(my_starts, tt, init=True)
-        return P.multistart.gather_boxes(tt, nstart, dist, dst=0, shards=shards, path=gather["path"])
+    # per-rank diagnostics of the timed steps (N > 1): where a step's time goes on every rank
+    phase = {"solve_s": 0.0, "gather_s": 0.0, "solve_device_ms": 0.0, "fallbacks": 0, "steps": 0}
+
+    def step(timed=False):
+        t_a = time.perf_counter()
+        sol.solve_device(my_starts, tt, init=True)      # (returns when the boxes are converged: the library synchronises)
+        t_b = time.perf_counter()
+        out_ = P.multistart.gather_boxes(tt, nstart, dist, dst=0, shards=shards, path=gather["path"], group=rccl)
+        if timed:
+            if dist is not None:
+                torch.cuda.synchronize()                # (this rank's part of the gather has completed)
+            st_ = sol.stats()
+            phase["solve_s"] += t_b - t_a
+            phase["gather_s"] += time.perf_counter() - t_b
+            phase["solve_device_ms"] += st_["solve_ms"]
+            phase["fallbacks"] += int(st_.get("fallbacks", 0))
+            phase["steps"] += 1
+        return out_
 
     def fence():
         if dist is not None:
-            dist.barrier(group=ctl)
+            dist.barrier()
         torch.cuda.synchronize()
 
     if dist is not None and gather["path"] == "device":
@@ -489,7 +567,7 @@ def main():
         except Exception as e:          # noqa: BLE001
             err = f"device gather failed on rank {rank}: {type(e).__name__}: {e}"[:300]
         errs = [None] * world
-        dist.all_gather_object(errs, err, group=ctl)
+        dist.all_gather_object(errs, err)
         bad = [x for x in errs if x]
         if bad:
             gather = dict(gather, path="host", why=bad[0])
@@ -500,24 +578,33 @@ def main():
     sweeps_local = 0            # passes launched (a pass relaxes only what is due)
     relaxed_local = 0           # cells actually relaxed against the whole star
     for _ in range(args.steps):
-        step()
+        step(timed=True)
         st_ = sol.stats()
         sweeps_local += st_["sweeps_total"]
         relaxed_local += st_["cells_relaxed"]
     fence()
     dt = time.perf_counter() - t0
+    dt_local = dt
 
     # max over ranks of the elapsed time, sum over ranks of the passes executed
-    agg = torch.tensor([dt, float(sweeps_local), float(relaxed_local)], dtype=torch.float64,
-                       device=dev if args.backend == "nccl" else "cpu")
+    agg = torch.tensor([dt, float(sweeps_local), float(relaxed_local)], dtype=torch.float64)
+    ranks_info = None
     if dist is not None:
-        if ctl is not None:
-            agg = agg.cpu()
         tmax = agg[:1].clone()
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX, group=ctl)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         ssum = agg[1:].clone()
-        dist.all_reduce(ssum, op=dist.ReduceOp.SUM, group=ctl)
+        dist.all_reduce(ssum, op=dist.ReduceOp.SUM)
         dt, sweeps_all, relaxed_all = float(tmax.item()), float(ssum[0].item()), float(ssum[1].item())
+        # every rank's share of a step, for the line: the first multi-GPU run has to say WHY it scales as it does
+        k = max(phase["steps"], 1)
+        mine_info = {"rank": rank, "device": dev_index, "starts": len(mine), "start_ids": [int(x) for x in mine],
+                     "shard_cost_estimate": round(sum(P.multistart.start_cost(starts[i], (nx, ny, nz)) for i in mine), 1),
+                     "solve_ms": phase["solve_s"] / k * 1e3, "solve_device_ms": phase["solve_device_ms"] / k,
+                     "gather_ms": phase["gather_s"] / k * 1e3, "step_ms": dt_local / max(args.steps, 1) * 1e3,
+                     "full_sweep_equivalents": relaxed_local / cells / max(args.steps, 1),
+                     "fallbacks": phase["fallbacks"]}
+        ranks_info = [None] * world
+        dist.all_gather_object(ranks_info, mine_info)
     else:
         sweeps_all, relaxed_all = float(sweeps_local), float(relaxed_local)
 
@@ -528,6 +615,7 @@ def main():
     st = sol.stats()
     sol.set_option(P.OPT_TIMING, 0)
 
+    failed = False
     if rank == 0:
         kern_s = st["sweep_kernel_ms"] / 1e3
         launches = max(st["launches"], 1)
@@ -566,11 +654,12 @@ def main():
                                    f"{nstart} starts (start-{args.starts}), converged multi-start solve",
                        "grid": [nx, ny, nz], "star_offsets": int(len(offs)), "starts": int(nstart),
                        "starts_per_gpu": len(mine), "parallelism": f"starts sharded over {world} GPU(s)",
-                       "gather": gather,
+                       "gather": gather_report(gather, ranks_info, shards, cells),
+                       "ranks": ranks_info,
                        "kernel_variant": st["kernel_variant"],
                        "driver": ("one launch per solve (ring planners + workers, convergence detected on the device)"
                                   if st["kernel_variant"] in (2, 3) and st["launches"] == 1 else "a launch (pair) per pass / hyperplane, convergence tested on the host"),
-                       "fallbacks": int(st.get("fallbacks", 0)),
+                       "fallbacks": int(st.get("fallbacks", 0)) + (sum(r["fallbacks"] for r in ranks_info) if ranks_info else phase["fallbacks"]),
                        "library": os.path.relpath(P._lib.LIB_PATH, ROOT),
                        "passes_per_start_mean": sweeps_all / args.steps / nstart,
                        "full_sweep_equivalents_per_start_mean": relaxed_all / cells / args.steps / nstart},
@@ -617,15 +706,27 @@ def main():
                 tts_["cpu_basis"] = (f"measured seconds per reference-order sweep on this host x the sweeps the "
                                      f"unmodified reference needed (mean {mean_sweeps:.1f} over {len(ref)} of the "
                                      f"{nstart} starts, tests/golden/big_digests.json); one start per core")
+        if args.cpu_b2 and small:
+            out["cpu_baseline_b2"] = cpu_leg_b2(P)
         if hbm_regime_wanted(args) and world == 1:
             sol.close()
             del tt, v_dev
             torch.cuda.empty_cache()
             out["roofline_hbm_regime"] = hbm_regime(P, torch, dev, dev_index, hbm_traffic, not args.no_cpu)
+        if out["config"]["fallbacks"]:
+            # a one-launch solve that gives up is finished by the second driver with the same result - but not in the
+            # time this line is about: the run counts as failed
+            out["error"] = f"{out['config']['fallbacks']} solve(s) of the measured steps fell back to the pass / hyperplane driver"
+            failed = True
         print(json.dumps(out), flush=True)
     sol.close()
     if dist is not None:
+        flag = [failed]
+        dist.broadcast_object_list(flag, src=0)
+        failed = bool(flag[0])
         dist.destroy_process_group()
+    if failed:
+        sys.exit(3)
 
 
 if __name__ == "__main__":

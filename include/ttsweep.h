@@ -34,8 +34,9 @@
 extern "C" {
 #endif
 
-#define TTSWEEP_ABI_VERSION 5      /* 5 (round 4): + ttsweep_get_changed, ttsweep_solve_multi_device, stats.fallbacks (in the struct's former
-                                      padding), options 19-21; every version-4 caller runs unchanged */
+#define TTSWEEP_ABI_VERSION 6      /* 6 (round 5): + ttsweep_solve_multi_changed, options 22-23; 5 (round 4): + ttsweep_get_changed,
+                                      ttsweep_solve_multi_device, stats.fallbacks (in the struct's former padding),
+                                      options 19-21; every version-4 caller runs unchanged */
 
 /* Forward-star entry: same layout as `struct FS`
  * (serial_new/sweep-tt-multistart.c:46-49).  d must already hold
@@ -151,6 +152,21 @@ typedef struct ttsweep_ctx ttsweep_ctx;
                                          values it has just stored - before it is handed back (-1, the default: 2 for
                                          solves of 2 and more starts, 0 for a single start; 0 .. 8) */
 
+#define TTSWEEP_OPT_ASYNC_HANDOFF 22  /* schedule only, never the result (STRIP kernel, one launch per solve): direct
+                                         hand-off - a worker that has improved a plane not only tells the units that
+                                         stage it, it also puts the idle ones among them (inside the distance gate) into
+                                         the ring itself instead of leaving them to the planner's next scan (1), and
+                                         likewise its own unit when bits arrived while it was being relaxed (2; 3 = both).
+                                         -1 (default): the library chooses by the size of the solve (small shards: 3);
+                                         0 = only the planners publish */
+
+#define TTSWEEP_OPT_ASYNC_WAVES 23    /* schedule only, never the result (STRIP kernel, one launch per solve, one-plane
+                                         units): wavefronts that relax a unit - 4 (two workgroups per CU, two units per CU
+                                         at a time: throughput) or 8 (one workgroup per CU, all of a CU's wavefronts on
+                                         one unit, four planes staged ahead: a hop of the front takes about half as
+                                         long - for shards too small to fill the machine).  -1 (default): by the size
+                                         of the solve */
+
 #define TTSWEEP_KERNEL_AUTO       0
 #define TTSWEEP_KERNEL_CELL       1   /* one thread per cell, star from global memory */
 #define TTSWEEP_KERNEL_STRIP      2   /* LDS-staged plane slabs, register strips */
@@ -206,7 +222,7 @@ int ttsweep_set_velocity_device(ttsweep_ctx *ctx, const float *v_dev);
  * (the two outcomes `anychange != 0` / `== 0` of :163-166), < 0 on error.
  * Replaces: the whole `while (anychange)` loop of :151-170 over all starts.
  * A call with exactly the arrays and starts of the previous successful call on this context,
- * their contents bit for bit as that call left them (checked with a 64-bit digest of every
+ * their contents bit for bit as that call left them (checked with a 128-bit digest of every
  * box; velocity, star and kernel unchanged), is answered with 0 without any device work: it
  * is the confirming pass of a reference-style driver loop. */
 int ttsweep_solve(ttsweep_ctx *ctx, int nstart, const ttsweep_start *starts,
@@ -258,6 +274,12 @@ int ttsweep_validate_device(ttsweep_ctx *ctx, const ttsweep_start *start, const 
 int ttsweep_solve_multi(int ndev, const int *devices, int nx, int ny, int nz,
                         const ttsweep_fs *fs, int starstart, int starstop, const float *v_host,
                         int nstart, const ttsweep_start *starts, float *const *tt_host);
+/* ... with the per-start outcome (ABI 6): changed[s] = 1 when a travel time of start s improved, 0 when its box was
+ * at its fixed point already - what the reference's driver prints and sums as changed[s]
+ * (serial_new/sweep-tt-multistart.c:158-164); changed may be NULL (then this is ttsweep_solve_multi). */
+int ttsweep_solve_multi_changed(int ndev, const int *devices, int nx, int ny, int nz,
+                                const ttsweep_fs *fs, int starstart, int starstop, const float *v_host,
+                                int nstart, const ttsweep_start *starts, float *const *tt_host, int *changed);
 
 /* The same with the result set RESIDENT ON A DEVICE - the step the reference's MPI version left as a TODO
  * (mpi/backup.c:381-386: "gather the ttboxes"; its CUDA version moves boxes between devices with peer copies,

@@ -23,7 +23,7 @@ def test_library_exports_every_declared_symbol(pkg):
     for n in names:
         assert hasattr(L, n), f"{n} declared in include/ttsweep.h but not exported"
         assert n in bound, f"{n} has no ctypes binding"
-    assert L.ttsweep_abi_version() == 5
+    assert L.ttsweep_abi_version() == 6
 
 
 def test_struct_layouts_match_reference_structs(pkg):

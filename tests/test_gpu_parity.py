@@ -835,6 +835,25 @@ SCHEDULES = [
     (1, {"OPT_ASYNC_INUNIT": 1, "OPT_PAIR_MIN_STARTS": 0}),
     (1, {"OPT_ASYNC_INUNIT": 8, "OPT_DEFER_MARGIN_MILLI": 1000}),
     (1, {"OPT_ASYNC_INUNIT": 3, "OPT_PAIR_MIN_STARTS": 0, "OPT_ASYNC_POLICY": 0}),
+    # direct hand-off (round 5): workers publish successor units (1), their own unit (2), both; with every ring policy
+    # that allows it, a tiny ring fill, no gate, eager deferral, in-unit passes, one- and two-plane units
+    (1, {"OPT_ASYNC_HANDOFF": 1}),
+    (1, {"OPT_ASYNC_HANDOFF": 2}),
+    (1, {"OPT_ASYNC_HANDOFF": 3}),
+    (1, {"OPT_ASYNC_HANDOFF": 3, "OPT_PAIR_MIN_STARTS": 0}),
+    (1, {"OPT_ASYNC_HANDOFF": 3, "OPT_ASYNC_POLICY": 0, "OPT_ASYNC_LOW": 1, "OPT_ASYNC_HIGH": 2}),
+    (1, {"OPT_ASYNC_HANDOFF": 3, "OPT_GATE_SPEED_MILLI": 0, "OPT_DEFER_MARGIN_MILLI": -4000}),
+    (1, {"OPT_ASYNC_HANDOFF": 1, "OPT_ASYNC_GATE_MILLI": 100, "OPT_ASYNC_GATE_FAST_MILLI": 100, "OPT_ASYNC_INUNIT": 2}),
+    (1, {"OPT_ASYNC_HANDOFF": 3, "OPT_ASYNC_SPECIAL": 1, "OPT_DEFER_MARGIN_MILLI": -1000000000, "OPT_QUEUES": 1}),
+    (1, {"OPT_ASYNC_HANDOFF": 3, "OPT_ASYNC_POLICY": 2, "OPT_ASYNC_WINDOW_MILLI": 3000}),     # (policy 2: hand-off stays off)
+    # the latency instance (round 5): a unit relaxed by eight waves, four slabs in flight (one-plane units only: with
+    # units of two planes the option is ignored)
+    (1, {"OPT_ASYNC_WAVES": 8}),
+    (1, {"OPT_ASYNC_WAVES": 8, "OPT_ASYNC_INUNIT": 2}),
+    (1, {"OPT_ASYNC_WAVES": 8, "OPT_ASYNC_HANDOFF": 3, "OPT_ASYNC_INUNIT": 3, "OPT_DEFER_MARGIN_MILLI": 0}),
+    (1, {"OPT_ASYNC_WAVES": 8, "OPT_ASYNC_POLICY": 0, "OPT_ASYNC_LOW": 1, "OPT_ASYNC_HIGH": 2, "OPT_ASYNC_SPECIAL": 1}),
+    (1, {"OPT_ASYNC_WAVES": 8, "OPT_PAIR_MIN_STARTS": 0}),
+    (1, {"OPT_ASYNC_WAVES": 4, "OPT_PAIR_MIN_STARTS": 1000000}),
     (0, {"OPT_DEFER_MARGIN_MILLI": -1000000000}),
     (0, {"OPT_DEFER_MARGIN_MILLI": -4000}),
     (0, {"OPT_DEFER_MARGIN_MILLI": 0, "OPT_PAIR_MIN_STARTS": 0}),
@@ -1072,10 +1091,18 @@ def test_solve_multi_shards_starts_over_devices(P, golden24):
             tt = np.full(golden24.v.shape, np.inf, dtype=np.float32)
             tt[tuple(st)] = 0
             tts.append(tt)
-        assert P.solve_multi(devices, golden24.v, fs, starts, tts) == 1
+        changed = []
+        assert P.solve_multi(devices, golden24.v, fs, starts, tts, changed=changed) == 1
+        assert changed == [1] * len(starts)
         for k, tt in zip(keys, tts):
             assert_bit_equal(tt, golden24.z[f"tt_{k}"], k)
         assert P.solve_multi(devices, golden24.v, fs, starts, tts) == 0
+        # the per-start outcome (serial_new/...:158-164: changed[s]): one box reset, the others at their fixed point
+        tts[2][...] = np.inf
+        tts[2][tuple(starts[2])] = 0
+        assert P.solve_multi(devices, golden24.v, fs, starts, tts, changed=changed) == 1
+        assert changed == [0, 0, 1, 0]
+        assert_bit_equal(tts[2], golden24.z[f"tt_{keys[2]}"], keys[2])
 
 
 def test_context_reuse_and_edge_arguments(P, golden24, oracle):

@@ -105,6 +105,37 @@ def test_host_program_with_STARTMAX_starts(exe, pkg, oracle, tmp_path):
         assert np.array_equal(box.view(np.uint32), want.view(np.uint32)), s
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("which", ["1", "24"])
+def test_host_program_full_size_digests(exe, pkg, tmp_path, which):
+    """BASELINE configs 1 and 3 through the drop-in main() itself (serial_new/sweep-tt-multistart.c:70-195 as the
+    caller, :151-170 as the loop being replaced): the synthetic 241x241x51 model as a VBOX file, docs/818-FS.txt,
+    docs/start-1 / start-24 verbatim; every travel-time volume the program writes is, bit for bit, the box the
+    UNMODIFIED reference converged to (SHA-256 recorded from oracle/_ref by tests/golden/make_golden.py)."""
+    import hashlib
+    import json
+    digests = json.load(open(os.path.join(ROOT, "tests", "golden", "big_digests.json")))
+    v = pkg.inputs.velocity_model(241, 241, 51, 20160507)
+    pkg.inputs.write_vbox(str(tmp_path / "model.vbox"), v)
+    starts = pkg.inputs.read_triples(pkg.inputs.starts_path(which))
+    env = dict(os.environ, TTSWEEP_NO_OUTPUT="1", TTSWEEP_BINARY_OUTPUT="tt-")
+    r = subprocess.run([exe, "model.vbox", pkg.inputs.star_path("818"), pkg.inputs.starts_path(which)], cwd=tmp_path,
+                       env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    out = r.stdout
+    assert "Velocity model dimensions: 241 x 241 x 51" in out and "Forward star size: 818" in out
+    assert f"starting point {len(starts) - 1}:" in out
+    assert "sweep 2 finished: anychange = 0" in out and "sweep 3 begin" not in out
+    changed = [l for l in out.splitlines() if l.startswith(">>> start")]
+    n = len(starts)
+    assert changed == [f">>> start {s}: changed == 1" for s in range(n)] + [f">>> start {s}: changed == 0" for s in range(n)]
+    for s, st in enumerate(starts):
+        want = digests["syn241_818_%d_%d_%d" % tuple(int(x) for x in st)]["sha256"]
+        origin, box = pkg.inputs.read_vbox(str(tmp_path / f"tt-{s}.vbox"))
+        assert origin == (1, 1, 1) and box.shape == v.shape and box.dtype == np.float32
+        assert hashlib.sha256(np.ascontiguousarray(box).tobytes()).hexdigest() == want, (s, tuple(st))
+
+
 def test_host_program_rejects_bad_input(exe, tmp_path):
     r = subprocess.run([exe], cwd=tmp_path, capture_output=True, text=True)
     assert r.returncode == 1 and "usage" in r.stdout

@@ -70,6 +70,8 @@ SYMBOLS = [
                                          C.c_void_p]),
     ("ttsweep_solve_multi", C.c_int, [C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p,
                                       C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
+    ("ttsweep_solve_multi_changed", C.c_int, [C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p,
+                                              C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     ("ttsweep_sweepXYZ", C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p,
                                    C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
     ("ttsweep_build_pull_star", C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int]),
@@ -83,6 +85,8 @@ OPT_ASYNC, OPT_ASYNC_LOW, OPT_ASYNC_HIGH, OPT_ASYNC_SPECIAL, OPT_ASYNC_POLICY, O
 OPT_TILE_IN_PLACE = 19
 OPT_QUEUES = 20
 OPT_ASYNC_INUNIT = 21
+OPT_ASYNC_HANDOFF = 22
+OPT_ASYNC_WAVES = 23
 KERNEL_AUTO, KERNEL_CELL, KERNEL_STRIP, KERNEL_TILE = 0, 1, 2, 3
 
 

@@ -178,6 +178,7 @@ void ttsweep_destroy(ttsweep_ctx *ctx)
     (void)hipFree(ctx->d_cell_entries);
     (void)hipFree(ctx->d_fwd_entries);
     for (StripItem *d : ctx->d_strip_items) (void)hipFree(d);
+    (void)hipFree(ctx->d_strip_items_lat);
     (void)hipFree(ctx->d_T);
     (void)hipFree(ctx->d_starts);
     (void)hipFree(ctx->d_active);
@@ -314,6 +315,15 @@ int ttsweep_set_option(ttsweep_ctx *ctx, int key, long long value)
     case TTSWEEP_OPT_ASYNC_INUNIT:
         if (value < -1 || value > 8) return set_error("in-unit passes must be -1 (default rule) or 0 .. 8");
         ctx->async_inunit = (int)value;
+        return 0;
+    case TTSWEEP_OPT_ASYNC_WAVES:
+        if (value != -1 && value != ttsweep::STRIP_NS && value != ttsweep::STRIP_NS_LAT)
+            return set_error("waves per unit must be -1 (default rule), %d or %d", (int)ttsweep::STRIP_NS, (int)ttsweep::STRIP_NS_LAT);
+        ctx->async_waves = (int)value;
+        return 0;
+    case TTSWEEP_OPT_ASYNC_HANDOFF:
+        if (value < -1 || value > 3) return set_error("hand-off must be -1 (default rule) or a sum of 1 (neighbours) and 2 (own unit)");
+        ctx->async_handoff = (int)value;
         return 0;
     case TTSWEEP_OPT_QUEUES:
         if (value < 1 || value > ttsweep::UNITQ_LISTS) return set_error("queues must be 1 .. %d", (int)ttsweep::UNITQ_LISTS);
@@ -502,12 +512,16 @@ int ttsweep_solve_device(ttsweep_ctx *ctx, int nstart, const ttsweep_start *star
 
 extern "C" {
 
-// 64-bit digest of a box (the bit patterns of its floats), for the "nothing has changed since
+// 128-bit digest of a box (the bit patterns of its floats), for the "nothing has changed since
 // this context returned these boxes" test of ttsweep_solve: four independent multiply-xorshift
-// lanes over 64-bit words, memory-bound.
-static uint64_t box_digest(const float *box, size_t cells)
+// lanes over 64-bit words (a lane's step is a bijection of its state for every word, and of the
+// word for every state), memory-bound; the 256 bits of lane state are folded into two 64-bit
+// words in two different ways.  (Round 4 kept 64 bits: the one place where the boundary could,
+// with probability 2^-64 per edited box, answer "0" for a box the caller has changed.)
+typedef ttsweep_ctx::Digest Digest;
+static Digest box_digest(const float *box, size_t cells)
 {
-    const uint64_t K = 0x9E3779B97F4A7C15ull;
+    const uint64_t K = 0x9E3779B97F4A7C15ull, K2 = 0xC2B2AE3D27D4EB4Full;
     uint64_t h[4] = {K, K ^ 0x1111111111111111ull, K ^ 0x2222222222222222ull, K ^ 0x3333333333333333ull};
     const size_t words = cells / 2;
     size_t i = 0;
@@ -525,15 +539,19 @@ static uint64_t box_digest(const float *box, size_t cells)
         h[i & 3] = (h[i & 3] ^ w) * K;
         h[i & 3] ^= h[i & 3] >> 29;
     }
-    uint64_t out = cells;
-    for (int k = 0; k < 4; k++) out = (out ^ h[k]) * K + (out >> 31);
+    Digest out{cells, ~(uint64_t)cells};
+    for (int k = 0; k < 4; k++) out.a = (out.a ^ h[k]) * K + (out.a >> 31);
+    for (int k = 3; k >= 0; k--) {
+        const uint64_t r = (h[k] << 23) | (h[k] >> 41);
+        out.b = (out.b ^ r) * K2 + (out.b >> 29);
+    }
     return out;
 }
 
 // Digests of n boxes, a few host threads side by side.
-static std::vector<uint64_t> box_digests(float *const *boxes, int n, size_t cells)
+static std::vector<Digest> box_digests(float *const *boxes, int n, size_t cells)
 {
-    std::vector<uint64_t> out(n, 0);
+    std::vector<Digest> out(n);
     const int nthreads = std::max(1, std::min({n, 4, (int)std::thread::hardware_concurrency()}));
     std::vector<std::thread> pool;
     for (int t = 0; t < nthreads; t++)
@@ -557,7 +575,7 @@ int ttsweep_solve(ttsweep_ctx *ctx, int nstart, const ttsweep_start *starts,
     // hear "0".  When every box of the call is bit for bit what this context last wrote into
     // that very array for that very start (velocity unchanged since; the fixed point depends
     // on nothing else a context can change), it is the fixed point already and a solve would
-    // store nothing: answer without touching the device.  (The comparison is a 64-bit digest
+    // store nothing: answer without touching the device.  (The comparison is a 128-bit digest
     // of every box, not a promise by the caller.)
     {
         bool known = !ctx->solved.empty();
@@ -567,7 +585,7 @@ int ttsweep_solve(ttsweep_ctx *ctx, int nstart, const ttsweep_start *starts,
                  && it->second.start.j == starts[s].j && it->second.start.k == starts[s].k;
         }
         if (known) {
-            const std::vector<uint64_t> now = box_digests(tt_host, nstart, cells);
+            const std::vector<Digest> now = box_digests(tt_host, nstart, cells);
             for (int s = 0; s < nstart && known; s++) known = now[s] == ctx->solved[tt_host[s]].digest;
         }
         if (known) {
@@ -656,7 +674,7 @@ int ttsweep_solve(ttsweep_ctx *ctx, int nstart, const ttsweep_start *starts,
         lap("solve");
         // what the caller will hold afterwards: the fixed point of every start - digested box by
         // box as the downloads complete (an event per box, a few host threads)
-        std::vector<uint64_t> dig(n, 0);
+        std::vector<Digest> dig(n);
         std::vector<hipEvent_t> landed;
         if (rc > 0) {       // (rc == 0: nothing was stored, the caller's boxes are the result already)
             for (int s = 0; s < n; s++) {
@@ -872,13 +890,13 @@ int ttsweep_solve_multi_device(int ndev, const int *devices, int nx, int ny, int
                 my_boxes.push_back(local[d] ? local[d] + (size_t)k * cells : tt_root[shard[d][k]]);
             }
             if (r == 0) r = ttsweep_solve_device(ctx, n, my_starts.data(), my_boxes.data(), /*init=*/1);
-            if (r >= 0) {
+            if (r >= 0 && ctx) {
                 std::vector<int> ch(n, 0);
                 (void)ttsweep_get_changed(ctx, ch.data(), n);
                 for (int k = 0; k < n; k++) changed_all[shard[d][k]] = ch[k];
             }
             if (r < 0) err[d] = ttsweep_last_error();       // thread-local text
-            ttsweep_destroy(ctx);
+            if (ctx) ttsweep_destroy(ctx);
             rc[d] = r;
         });
     }
@@ -941,6 +959,14 @@ int ttsweep_solve_multi_device(int ndev, const int *devices, int nx, int ny, int
         // (a refused communicator or a failed group: the peer copies below move every box again)
     }
     if (!done) {
+        // (a group that failed part-way may have receives into tt_root in flight on any stream: every device is
+        // drained before the peer copies write the same slots)
+        for (int d = 0; d < ndev; d++) {
+            (void)hipSetDevice(devices[d]);
+            (void)hipStreamSynchronize(streams[d]);
+            (void)hipDeviceSynchronize();
+            (void)hipGetLastError();
+        }
         for (int d = 0; d < ndev; d++) {
             if (!local[d]) continue;
             (void)hipSetDevice(devices[0]);
@@ -962,7 +988,16 @@ int ttsweep_solve_multi(int ndev, const int *devices, int nx, int ny, int nz,
                         const ttsweep_fs *fs, int starstart, int starstop, const float *v_host,
                         int nstart, const ttsweep_start *starts, float *const *tt_host)
 {
+    return ttsweep_solve_multi_changed(ndev, devices, nx, ny, nz, fs, starstart, starstop, v_host, nstart, starts, tt_host,
+                                       nullptr);
+}
+
+int ttsweep_solve_multi_changed(int ndev, const int *devices, int nx, int ny, int nz,
+                                const ttsweep_fs *fs, int starstart, int starstop, const float *v_host,
+                                int nstart, const ttsweep_start *starts, float *const *tt_host, int *changed)
+{
     if (ndev <= 0 || !devices || !starts || !tt_host || nstart < 0) return set_error("bad arguments");
+    std::vector<int> changed_all(std::max(nstart, 0), 0);
     std::vector<int> rc(ndev, 0);
     std::vector<std::string> err(ndev);
     std::vector<std::thread> workers;
@@ -980,8 +1015,13 @@ int ttsweep_solve_multi(int ndev, const int *devices, int nx, int ny, int nz,
             int r = ctx ? ttsweep_set_velocity(ctx, v_host) : -1;
             if (r == 0)
                 r = ttsweep_solve(ctx, (int)my_starts.size(), my_starts.data(), my_boxes.data());
+            if (r >= 0 && ctx) {        // (the shard's boxes are distinct starts: no two threads write one slot)
+                std::vector<int> ch(my_starts.size(), r);
+                (void)ttsweep_get_changed(ctx, ch.data(), (int)ch.size());
+                for (size_t k = 0; k < ch.size(); k++) changed_all[shard[d][k]] = ch[k];
+            }
             if (r < 0) err[d] = ttsweep_last_error();       // thread-local text
-            ttsweep_destroy(ctx);
+            if (ctx) ttsweep_destroy(ctx);
             rc[d] = r;
         });
     }
@@ -991,6 +1031,7 @@ int ttsweep_solve_multi(int ndev, const int *devices, int nx, int ny, int nz,
         if (rc[d] < 0) return set_error("device %d: %s", devices[d], err[d].c_str());
         any |= rc[d];
     }
+    if (changed) for (int s = 0; s < nstart; s++) changed[s] = changed_all[s];
     return any;
 }
 

@@ -511,7 +511,10 @@ column_solve_kernel(const ColumnSolve P)
         CPROF_ADD(2, pt2 - pt1);
         int prof_runs = 0;
         (void)prof_runs;
-        if (e > P.max_sweeps) { col_fail(P, COL_ERR_CAP); break; }
+        // (the cap is raised only by a column that is about to RELAX a tile in a sweep beyond it - below -: a column of
+        // sweep max_sweeps + 1 can pass its poll before the last column of sweep max_sweeps has declared the start at
+        // rest, and has nothing due then)
+        const bool over = e > P.max_sweeps;
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
         const bool upvalid = valid && (lane == 1 || lane == 2);
         int known_up = 0;
@@ -574,6 +577,11 @@ column_solve_kernel(const ColumnSolve P)
             const unsigned avail = known_up >= 32 ? ~0u : ((1u << known_up) - 1u);
             const unsigned dm = (mask0 | upmask | pend) & avail & ~((1u << k) - 1u);
             if (dm == 0u) { k = known_up; continue; }
+            if (over) {         // a tile is due beyond the cap - unless the start has been declared at rest meanwhile
+                if (cld32(reinterpret_cast<const unsigned *>(P.done + s)) == 0u) col_fail(P, COL_ERR_CAP);
+                alive = false;
+                break;
+            }
             const int k0 = __builtin_ctz(dm);
             if (published < k0) {
                 if (lane == 0) __hip_atomic_store(prog + col, ((unsigned long long)col_key(e, k0) << 32) | mymask,
@@ -804,16 +812,20 @@ column_init_kernel(ColumnSolve P, const StartDesc *__restrict__ starts, int from
 
 int column_solve_wg_waves() { return CWG; }
 
+// The opt-in to more than 64 KB of dynamic LDS belongs to the CURRENT device: every context (one per device in
+// ttsweep_solve_multi / _multi_device, each on a thread of its own) asks for it with its device bound, and
+// launch_column_solve asks again on every launch, as launch_solve_units does - no process-wide flag.
+static hipError_t column_raise_lds()
+{
+    return hipFuncSetAttribute((const void *)column_solve_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, CWG * CLDSB);
+}
+
 hipError_t column_solve_wgs_per_cu(int *wgs)
 {
-    static bool raised = false;
-    if (!raised) {
-        const hipError_t e = hipFuncSetAttribute((const void *)column_solve_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, CWG * CLDSB);
-        if (e != hipSuccess) return e;
-        raised = true;
-    }
+    hipError_t e = column_raise_lds();
+    if (e != hipSuccess) return e;
     int n = 0;
-    const hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, (const void *)column_solve_kernel, 64 * CWG, CWG * CLDSB);
+    e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, (const void *)column_solve_kernel, 64 * CWG, CWG * CLDSB);
     if (e != hipSuccess) return e;
     *wgs = std::min(std::max(n, 1), (int)COL_WAVES / CWG);
     return hipSuccess;
@@ -834,6 +846,8 @@ hipError_t launch_column_solve(const ColumnSolve &P, int nblocks, hipStream_t st
         || P.L.p[2] - P.L.lo[2] - P.NK * TILE_Z < CS || !P.tptr || P.ts1 % CS || P.ts0 % CS || P.tlo % CS
         || (P.tpad != 0 && P.tpad != 1) || (P.tpad == 0 && P.L.n[2] % TILE_Z))
         return hipErrorInvalidValue;
+    const hipError_t e = column_raise_lds();
+    if (e != hipSuccess) return e;
     hipLaunchKernelGGL(column_solve_kernel, dim3((unsigned)nblocks), dim3(64 * CWG), CWG * CLDSB, st, P);
     return hipGetLastError();
 }

@@ -61,6 +61,9 @@ struct ttsweep_ctx {
 
     float *d_v = nullptr;                   // padded velocity
     bool have_v = false;
+    long long handoff_max_units = 0;            // (default rule) starts x one-plane units of a start below which workers hand on
+    int handoff_default = 3;
+    int async_handoff = -1;                     // workers publish successor units themselves (ASYNC_HANDOFF_*; -1: by the size of the solve)
     int async_inunit = -1;                      // in-unit passes of a one-launch STRIP solve (-1: by the number of starts)
     bool exact_half = false;                    // the velocity volume holds sub-limit values: CELL kernel, reference rounding
     int kernel_wanted = 0;                      // ... and the kernel to go back to when a volume without them arrives
@@ -75,6 +78,13 @@ struct ttsweep_ctx {
     // two planes (throughput mode); `np` is the mode of the solve in progress
     StripItem *d_strip_items[ttsweep::STRIP_PLANES] = {nullptr, nullptr};
     StripPlan plans[ttsweep::STRIP_PLANES]{};
+    // the latency instance (one-plane units, STRIP_NS_LAT waves): the same items in eight shares
+    StripItem *d_strip_items_lat = nullptr;
+    StripPlan plan_lat{};
+    int unitq_blocks_lat = 0;               // its resident grid (one workgroup per CU)
+    int async_waves = -1;                   // TTSWEEP_OPT_ASYNC_WAVES: 4 / 8 waves per unit; -1: by the size of the solve
+    long long lat_max_units = 16000;        // (default rule) starts x one-plane units of a start below which the latency instance runs
+                                            // (241x241x51: up to 4 starts; measured 1 start 5.9 -> 5.0 ms, 3 starts 7.5 -> 7.2, 8 starts 11.8 -> 15)
     int np = ttsweep::STRIP_PLANES;
     int pair_min_starts = -1;               // two-plane units from this many starts on; -1: by the supply of units
     long long pair_min_units = 80000;       //   (starts x one-plane units of a start; measured crossover)
@@ -160,7 +170,11 @@ struct ttsweep_ctx {
     // of the converged box)
     float *d_stage = nullptr;
     size_t stage_cap = 0;                   // boxes
-    struct SolvedBox { ttsweep_start start; unsigned long long digest; };
+    struct Digest {
+        unsigned long long a = 0, b = 0;
+        bool operator==(const Digest &o) const { return a == o.a && b == o.b; }
+    };
+    struct SolvedBox { ttsweep_start start; Digest digest; };
     std::unordered_map<const float *, SolvedBox> solved;
 
     // TTSWEEP_OPT_PREPASS: a context of its own for the sub-star that is relaxed first

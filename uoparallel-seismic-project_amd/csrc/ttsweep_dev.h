@@ -74,7 +74,15 @@ struct StartDesc {
 // STRIP kernel geometry (compile-time)
 // ---------------------------------------------------------------------------
 constexpr int STRIP_K = 16;                         // cells per thread along c
-constexpr int STRIP_NS = 4;                         // waves per workgroup
+constexpr int STRIP_NS = 4;                         // waves per workgroup (throughput instances: two workgroups per CU)
+constexpr int STRIP_NS_LAT = 8;                     // ... of the latency instance (one workgroup per CU relaxes one unit with all
+                                                    // of the CU's eight waves: small shards, ttsweep_driver.cpp)
+constexpr int STRIP_NS_MAX = 8;
+constexpr int STRIP_G = 1;                          // staged planes per barrier group of the throughput instances (2 G slabs in LDS)
+#ifndef TTSWEEP_G_LAT
+#define TTSWEEP_G_LAT 3
+#endif
+constexpr int STRIP_G_LAT = TTSWEEP_G_LAT;          // ... of the latency instance
 constexpr int STRIP_TB = 64;                        // lanes along b
 constexpr int STRIP_CF = 8;                         // halo in front of a strip window (>= max|dc|, multiple of 4)
 constexpr int STRIP_W = STRIP_K + 2 * STRIP_CF;     // neighbour window per (cell strip, column)
@@ -106,8 +114,9 @@ struct StripPlan {
     int first[STRIP_STAGED + 1];        // items of staged plane p are [first[p], first[p+1])
     int nent[STRIP_STAGED][STRIP_PLANES];   // offsets own plane j relaxes against staged plane p
     // the items of a staged plane are laid out so that wave w of the workgroup relaxes
-    // [first[p] + wsplit[p][w], first[p] + wsplit[p][w+1]) - four shares of nearly equal cost
-    unsigned char wsplit[STRIP_STAGED][STRIP_NS + 1];
+    // [first[p] + wsplit[p][w], first[p] + wsplit[p][w+1]) - ns shares of nearly equal cost
+    unsigned char wsplit[STRIP_STAGED][STRIP_NS_MAX + 1];
+    int ns;                             // waves per workgroup the shares are made for
 };
 
 // Unit grid of one start: plane groups (np planes each) along a x lane tiles along b x strips
@@ -161,15 +170,30 @@ struct UnitPassTail {
 // ring entry has been read) pair of agent-scope fences.
 constexpr int ASYNC_MAX_RINGS = 8;
 constexpr int ASYNC_CTL_STRIDE = 32;                    // 64-bit words per ring: [0] head | tail << 32 | done << 63,
-                                                        // [16] (low half) units completed
+                                                        // [8] (low half) squared gate radius of the ring's planner (float
+                                                        // bits; read by workers that hand units on), [16] (low half) units
+                                                        // completed
 constexpr int ASYNC_RING_STARTS = 32;                   // starts per ring, at most
 constexpr unsigned ASYNC_BUSY = 0x80000000u;            // pend word: the unit is queued or being relaxed
 constexpr unsigned ASYNC_UNIT_SPECIAL = 0xfffffu;       // ring entry: relax the start's dead-edge cells
 constexpr unsigned long long ASYNC_EXIT = ~0ull;
 constexpr int ASYNC_MAX_STARTS = 255;                   // (8 bits of a ring entry; 255 keeps ASYNC_EXIT apart)
-// ring entry: planes (16) | unit (20) << 16 | start (8) << 36 | position in the ring mod 2^19 << 44 | "tell
-// every unit at once" << 63 (set from the ring's first flush of deferred bits on)
+// ring entry: planes (16) | unit (20) << 16 | start (8) << 36 | position in the ring mod 2^18 << 44 | valid << 62 |
+// "tell every unit at once" << 63 (set from the ring's first flush of deferred bits on).  A slot is EMPTY (0) before
+// its first entry and again as soon as the worker that claimed its position has READ the entry (the worker stores 0
+// back); a producer writes a slot only when it is empty.  So a slot is never reused before its entry has been read,
+// however long a worker is held up between its claim and its look at the slot (round 4 bounded the reuse by a count
+// of completed entries, which a single pre-empted worker could slip through: the solve then ended at its wall-clock
+// limit).
+constexpr unsigned long long ASYNC_ENTRY_VALID = 1ull << 62;
+constexpr unsigned ASYNC_TAG_MASK = 0x3ffffu;
 enum : int { ASYNC_OK = 0, ASYNC_ERR_TIMEOUT = 1, ASYNC_ERR_CAP = 2 };
+// AsyncSolve::handoff bits: a worker that has improved a plane does not only set the plane bit in the pend words of
+// the units that stage it - it also takes the ones that are idle and inside the gate (compare-and-swap to BUSY) and
+// publishes them into the ring itself, instead of leaving them to the planner's next scan (1); the same for its own
+// unit when bits have arrived while it was relaxed (2).  The planner stays for everything else: the first units,
+// units behind the gate, rest detection.
+enum : int { ASYNC_HANDOFF_NEIGHBOURS = 1, ASYNC_HANDOFF_SELF = 2 };
 
 struct AsyncSolve {
     int nrings;
@@ -188,10 +212,11 @@ struct AsyncSolve {
     float window;                   // policy 2; <= 0: no gate
     int scan_slack;                 // list entries in front of the first unit with anything to do that a round still scans
     int inunit;                     // times a unit that improved is relaxed again against its own planes before it is handed back
+    int handoff;                    // ASYNC_HANDOFF_* (0: only the planners publish)
     int ring_off[ASYNC_MAX_RINGS], ring_len[ASYNC_MAX_RINGS];
     int ring_start_off[ASYNC_MAX_RINGS + 1];    // ring r serves starts ring_starts[ring_start_off[r] .. [r + 1])
     const int *ring_starts;
-    unsigned long long *entries;    // nrings x (cap_mask + 1), all ones before the launch
+    unsigned long long *entries;    // nrings x (cap_mask + 1), zero (every slot empty) before the launch
     unsigned long long *ctl;        // nrings x ASYNC_CTL_STRIDE, zero before the launch
     unsigned *status;               // [0]: ASYNC_OK or the first error
     long long timeout_ticks;        // wall-clock ticks (100 MHz) after which every wait gives up

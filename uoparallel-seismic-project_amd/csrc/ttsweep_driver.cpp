@@ -12,6 +12,10 @@
 
 namespace ttsweep {
 
+#ifdef TTSWEEP_DEBUG_ENV
+static int strip_flag_words_host(const DevLayout &L) { return L.n[0] * strip_btiles(L) * strip_cstrips(L); }
+#endif
+
 static int timed_event(ttsweep_ctx *ctx, hipEvent_t *out)
 {
     if (ctx->ev_used == ctx->ev_pool.size()) {
@@ -202,14 +206,21 @@ static bool use_async(ttsweep_ctx *ctx, int nstart)
 // pass driver).  Returns 1 / 0 (something improved / nothing did) or < 0.
 static int solve_async_strip(ttsweep_ctx *ctx, int nstart, std::vector<int> &sweeps)
 {
-    const StripPlan &plan = ctx->plans[ctx->np - 1];
     const int nunits = strip_units(ctx->L, ctx->np);
     if (ensure_unit_grid(ctx)) return -1;
+    // The latency instance (one-plane units relaxed by all eight waves of a CU, ttsweep_kernels.hip): for solves that
+    // offer too few units to fill the machine anyway - what bounds them is how long a hop of the front takes.
+    const bool lat = ctx->np == 1 && ctx->unitq_blocks_lat >= 4 * ASYNC_MAX_RINGS
+        && (ctx->async_waves >= 0 ? ctx->async_waves == STRIP_NS_LAT
+                                  : (long long)nstart * strip_units(ctx->L, 1) < ctx->lat_max_units);
+    const StripPlan &plan = lat ? ctx->plan_lat : ctx->plans[ctx->np - 1];
+    const StripItem *const d_items = lat ? ctx->d_strip_items_lat : ctx->d_strip_items[ctx->np - 1];
+    const int nblocks = lat ? ctx->unitq_blocks_lat : ctx->unitq_blocks;
     AsyncSolve as{};
     as.nrings = std::min(std::min(nstart, ctx->nlists), (int)ASYNC_MAX_RINGS);
     const int cap = 1 << 14;
     as.cap_mask = cap - 1;
-    const int workers = std::max((ctx->unitq_blocks - as.nrings) / as.nrings, 1);
+    const int workers = std::max((nblocks - as.nrings) / as.nrings, 1);
     as.low = ctx->async_low > 0 ? ctx->async_low : std::max(workers / 2, 8);
     as.high = ctx->async_high > 0 ? ctx->async_high : 2 * workers;
     as.high = std::max(as.high, as.low + 1);
@@ -266,6 +277,17 @@ static int solve_async_strip(ttsweep_ctx *ctx, int nstart, std::vector<int> &swe
     // two such passes - the planner hands out a third less -, 3 starts 7.85 -> 7.77, one start 6.38 -> 6.52:
     // profiles/r04_inunit.txt)
     as.inunit = ctx->async_inunit >= 0 ? ctx->async_inunit : (nstart >= 2 ? 2 : 0);
+    // Direct hand-off (ttsweep_dev.h, ASYNC_HANDOFF_*): for solves that cannot fill the machine - what bounds them is
+    // how fast good values travel from unit to unit, and every hop through the planner's scan costs a round of it.
+    // Every unit of a ring can sit in it at once (taken by a worker, not yet claimed): the rings must hold that.
+    {
+        long long longest_ring = 0;
+        for (int r = 0; r < as.nrings; r++) longest_ring = std::max<long long>(longest_ring, as.ring_len[r]);
+        const bool can = (as.policy == 1 || as.policy == 0) && longest_ring + 2 * ASYNC_RING_STARTS <= cap / 2;
+        const int want = ctx->async_handoff >= 0 ? ctx->async_handoff
+                       : ((long long)nstart * strip_units(ctx->L, 1) < ctx->handoff_max_units ? ctx->handoff_default : 0);
+        as.handoff = can ? want : 0;
+    }
     if (!cached && flat.size() > ctx->async_list_cap) {
         if (ctx->d_async_list) HIPCHK(hipFree(ctx->d_async_list));
         ctx->d_async_list = nullptr;
@@ -284,7 +306,7 @@ static int solve_async_strip(ttsweep_ctx *ctx, int nstart, std::vector<int> &swe
         HIPCHK(hipMemcpyAsync(ctx->d_async_ring_starts, ring_starts.data(), ring_starts.size() * sizeof(int),
                               hipMemcpyHostToDevice, ctx->stream));
     }
-    HIPCHK(hipMemsetAsync(ctx->d_async_entries, 0xff, (size_t)ASYNC_MAX_RINGS * cap * sizeof(unsigned long long), ctx->stream));
+    HIPCHK(hipMemsetAsync(ctx->d_async_entries, 0, (size_t)ASYNC_MAX_RINGS * cap * sizeof(unsigned long long), ctx->stream));
     HIPCHK(hipMemsetAsync(ctx->d_async_ctl, 0, (size_t)ASYNC_MAX_RINGS * ASYNC_CTL_STRIDE * sizeof(unsigned long long), ctx->stream));
     HIPCHK(hipMemsetAsync(ctx->d_async_status, 0, 8 * sizeof(unsigned), ctx->stream));
     HIPCHK(hipMemsetAsync(ctx->d_changed, 0, (size_t)nstart * sizeof(int), ctx->stream));
@@ -316,8 +338,8 @@ static int solve_async_strip(ttsweep_ctx *ctx, int nstart, std::vector<int> &swe
     tail.defer_margin = ctx->defer_margin;
     hipEvent_t e0, e1;
     if (ctx->timing && timed_event(ctx, &e0)) return -1;
-    HIPCHK(launch_solve_units(ctx->L, ctx->d_v, ctx->d_starts, ctx->unitq_blocks, ctx->d_changed,
-                              ctx->d_strip_items[ctx->np - 1], plan, tail, as, ctx->d_tile_flags,
+    HIPCHK(launch_solve_units(ctx->L, ctx->d_v, ctx->d_starts, nblocks, ctx->d_changed,
+                              d_items, plan, lat ? STRIP_NS_LAT : STRIP_NS, tail, as, ctx->d_tile_flags,
                               (long long)flag_words(ctx->L, ctx->kernel), ctx->stream));
     if (ctx->timing && timed_event(ctx, &e1)) return -1;
     ctx->stats.launches++;
@@ -332,6 +354,51 @@ static int solve_async_strip(ttsweep_ctx *ctx, int nstart, std::vector<int> &swe
     if (ctx->h_async_status[0] == ASYNC_ERR_CAP)
         return set_error("a start did not converge in %lld sweeps", ctx->max_sweeps);
     if (ctx->h_async_status[0] != ASYNC_OK) {
+#ifdef TTSWEEP_DEBUG_ENV
+        {   // what the rings and the activity words looked like when the launch gave up
+            std::vector<unsigned long long> ctl((size_t)ASYNC_MAX_RINGS * ASYNC_CTL_STRIDE);
+            (void)hipMemcpy(ctl.data(), ctx->d_async_ctl, ctl.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost);
+            for (int r = 0; r < as.nrings; r++) {
+                const unsigned long long x = ctl[(size_t)r * ASYNC_CTL_STRIDE];
+                float g;
+                const unsigned gb = (unsigned)ctl[(size_t)r * ASYNC_CTL_STRIDE + 8];
+                memcpy(&g, &gb, sizeof g);
+                fprintf(stderr, "  ring %d: head %u tail %u done %d completed %u gate_r2 %g | stored by the planner %llu, handed off %llu (reserved %llu), consumed %llu, reserved by the planner %llu (negative %llu)\n", r, (unsigned)x,
+                        (unsigned)(x >> 32) & 0x7fffffffu, (int)(x >> 63), (unsigned)ctl[(size_t)r * ASYNC_CTL_STRIDE + 16], g,
+                        ctl[(size_t)r * ASYNC_CTL_STRIDE + 24], ctl[(size_t)r * ASYNC_CTL_STRIDE + 25], ctl[(size_t)r * ASYNC_CTL_STRIDE + 27],
+                        ctl[(size_t)r * ASYNC_CTL_STRIDE + 26], ctl[(size_t)r * ASYNC_CTL_STRIDE + 28], ctl[(size_t)r * ASYNC_CTL_STRIDE + 29]);
+            }
+            const size_t fw = flag_words(ctx->L, ctx->kernel);
+            const int nflag = strip_flag_words_host(ctx->L);
+            std::vector<int> fl(fw);
+            for (int s = 0; s < nstart; s++) {
+                (void)hipMemcpy(fl.data(), ctx->d_tile_flags + (size_t)s * fw, fw * sizeof(int), hipMemcpyDeviceToHost);
+                int busy = 0, bits = 0, defer = 0, first_busy = -1, first_bits = -1;
+                for (int u = 0; u < nunits; u++) {
+                    const unsigned w = (unsigned)fl[2 * nflag + u];
+                    if (w & ASYNC_BUSY) { busy++; if (first_busy < 0) first_busy = u; }
+                    if (w & ~ASYNC_BUSY) { bits++; if (first_bits < 0) first_bits = u; }
+                    if (fl[u]) defer++;
+                }
+                fprintf(stderr, "  start %d: %d units busy (first %d), %d with plane bits (first %d, word %08x), %d with deferred bits\n",
+                        s, busy, first_busy, bits, first_bits, first_bits >= 0 ? (unsigned)fl[2 * nflag + first_bits] : 0u, defer);
+            }
+            std::vector<unsigned long long> ent((size_t)(as.cap_mask + 1));
+            for (int r = 0; r < as.nrings; r++) {
+                (void)hipMemcpy(ent.data(), ctx->d_async_entries + (size_t)r * (as.cap_mask + 1), ent.size() * 8, hipMemcpyDeviceToHost);
+                int full = 0;
+                for (size_t i = 0; i < ent.size(); i++) {
+                    const unsigned long long e = ent[i];
+                    if (e == 0ull) continue;
+                    full++;
+                    fprintf(stderr, "  ring %d slot %zu: planes %04x unit %u start %u tag %u valid %d nodefer %d\n", r, i,
+                            (unsigned)(e & 0xffffu), (unsigned)((e >> 16) & 0xfffffu), (unsigned)((e >> 36) & 0xffu),
+                            (unsigned)((e >> 44) & ASYNC_TAG_MASK), (int)((e >> 62) & 1), (int)(e >> 63));
+                }
+                fprintf(stderr, "  ring %d: %d slots hold an entry\n", r, full);
+            }
+        }
+#endif
         set_error("the one-launch solve gave up (code %u)", ctx->h_async_status[0]);
         return -2;      // (the boxes hold valid upper bounds: the caller goes on with the pass driver)
     }
@@ -496,15 +563,29 @@ static int solve_column(ttsweep_ctx *ctx, int nstart, bool from_box, float *cons
     HIPCHK(launch_column_init(C, ctx->d_starts, from_box, ctx->stream));
     hipEvent_t e0, e1;
     if (ctx->timing && timed_event(ctx, &e0)) return -1;
-    HIPCHK(launch_column_solve(C, (int)blocks, ctx->stream));
+    {   // (a launch that the device refuses - e.g. the LDS opt-in - leaves the boxes untouched: the hyperplane driver runs)
+        const hipError_t le = launch_column_solve(C, (int)blocks, ctx->stream);
+        if (le != hipSuccess) {
+            (void)hipGetLastError();
+            set_error("the column launch failed (%s)", hipGetErrorString(le));
+            return -2;
+        }
+    }
     if (ctx->timing && timed_event(ctx, &e1)) return -1;
     ctx->stats.launches++;
     HIPCHK(hipMemcpyAsync(ctx->h_col_status, ctx->d_col_status, 8 * sizeof(unsigned), hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipMemcpyAsync(ctx->h_col_done, ctx->d_col_done, (size_t)nstart * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipMemcpyAsync(ctx->h_changed, ctx->d_changed, (size_t)nstart * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
-    if (ctx->h_col_status[0] == COL_ERR_CAP)
+    if (ctx->h_col_status[0] == COL_ERR_CAP) {
+        // (the launch counts sweeps in COL_MAX_SWEEPS slots: a caller's cap beyond that is the hyperplane driver's to
+        // honour - it takes over from the boxes as they are)
+        if (ctx->max_sweeps > (long long)C.max_sweeps) {
+            set_error("the one-launch solve ran out of sweep slots (%d)", C.max_sweeps);
+            return -2;
+        }
         return set_error("a start did not converge in %lld sweeps", ctx->max_sweeps);
+    }
     if (ctx->h_col_status[0] != COL_DONE) {
         set_error("the one-launch solve gave up (code %u)", ctx->h_col_status[0]);
         return -2;

@@ -60,7 +60,7 @@ hipError_t launch_validate(const DevLayout &L, const float *v, const float *T, l
 // units that improved those planes: push_improved) and the distance gate has reached it; due
 // units are appended as (start, unit, planes) to the queue of their XCD, their word cleared.
 // sweep_units: a persistent grid (`nblocks` workgroups) drains the queues, own XCD first.
-size_t units_lds_bytes(const StripPlan &plan, int nb);
+size_t units_lds_bytes(int waves);
 int units_wgs_per_cu();     // persistent workgroups per CU the unit kernel is built for
 hipError_t launch_plan_pass(const DevLayout &L, const StartDesc *starts, const int2 *work,
                             long long nwork, int *changed, int4 *lists, int list_cap, int nlists,
@@ -72,8 +72,9 @@ hipError_t launch_sweep_units(const DevLayout &L, const float *v, const StartDes
                               const UnitPassTail &tail, hipStream_t st);
 // One launch per solve (AsyncSolve, ttsweep_dev.h): the first as.nrings workgroups plan, the others
 // relax; returns when every ring is at rest.  tail: only entries / nentries / max_box_cells are used.
+// waves: STRIP_NS (two workgroups per CU) or - units of one plane - STRIP_NS_LAT (the latency instance)
 hipError_t launch_solve_units(const DevLayout &L, const float *v, const StartDesc *starts, int nblocks,
-                              int *changed, const StripItem *items, const StripPlan &plan,
+                              int *changed, const StripItem *items, const StripPlan &plan, int waves,
                               const UnitPassTail &tail, const AsyncSolve &as, int *flags0, long long flags_stride,
                               hipStream_t st);
 // pend |= defer, defer = 0 for the units of the listed starts (np planes per unit); changed[s] |=

@@ -489,9 +489,9 @@ hipError_t launch_validate(const DevLayout &L, const float *v, const float *T, l
 
 // The first words of the dynamic LDS region carry workgroup-wide scalars (no static
 // __shared__ object: it would shift the 16-byte alignment of the dynamic base).
-constexpr int STRIP_LDS_HEAD = 16 + 64 + 32;    // words reserved in front of the slabs: 16 scalars, the
-                                            // waves' item ranges per staged plane, the offsets per
-                                            // staged plane and own plane (sweep_units_kernel)
+constexpr int strip_lds_head(int ns) { return 16 + 16 * ns + 32; }  // words reserved in front of the slabs: 16 scalars, the
+                                            // waves' item ranges per staged plane (16 per wave), 32 spare
+                                            // (sweep_units_kernel; a multiple of four: the slabs stay 16-byte aligned)
 // slab geometry (bytes): up to 64 + 2*7 rows, rounded up to 8, of 128 B for v, then for T
 constexpr int SLAB_MAX_ROWS8 = (STRIP_TB + 2 * STRIP_MAX_RA + 7) / 8 * 8;
 constexpr int SLAB_T_BYTES = SLAB_MAX_ROWS8 * STRIP_W * 4;
@@ -847,10 +847,70 @@ struct DeferRule {
     float margin;           // cells; < -1e30: nothing is deferred
 };
 
-template <int NP>
+// Hand-off (one launch per solve, AsyncSolve::handoff): what a worker needs to publish a unit into a ring itself.
+struct HandOff {
+    int on;                         // ASYNC_HANDOFF_* bits; 0: plane bits only, the planner does the rest
+    float gate_r2;                  // squared gate radius of the ring's planner (cells): units beyond it are left to it
+    unsigned long long *ht;         // the ring's head | tail << 32 | done << 63 word
+    unsigned long long *ents;       // the ring's slots
+    unsigned cap_mask;
+    unsigned long long tag_bits;    // start << 36 | "tell every unit at once" << 63 of the entries to publish
+    const unsigned *status;         // AsyncSolve::status
+    long long deadline;             // wall clock after which every wait gives up
+};
+
+// a ring slot as it is in memory: a read-modify-write that changes nothing (-DTTSWEEP_SLOT_RMW; experiment)
+__device__ __forceinline__ unsigned long long slot_load(const unsigned long long *p)
+{
+#ifdef TTSWEEP_SLOT_RMW
+    return __hip_atomic_fetch_or(const_cast<unsigned long long *>(p), 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#else
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#endif
+}
+
+// Publishes (unit, planes) at the tail of the ring: one returning add reserves the position, the entry goes into its
+// slot as soon as the slot is empty (it is, unless the ring has been lapped while a worker sat on the old entry).
+// The unit's pend word holds ASYNC_BUSY already (the caller's compare-and-swap).
+__device__ __forceinline__ void handoff_publish(const HandOff &ho, unsigned unit, unsigned planes)
+{
+    const unsigned long long old = atomicAdd(ho.ht, 1ull << 32);
+    const unsigned pos = (unsigned)(old >> 32) & 0x7fffffffu;
+#ifdef TTSWEEP_RING_DEBUG
+    atomicAdd(ho.ht + 27, 1ull);
+#endif
+    unsigned long long *const slot = ho.ents + (pos & ho.cap_mask);
+    for (unsigned spin = 0; slot_load(slot) != 0ull; spin++) {
+        if ((spin & 63u) == 63u
+            && (__hip_atomic_load(ho.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != ASYNC_OK || wall_clock64() > ho.deadline))
+            return;         // (the solve has failed or is about to: the pass driver rebuilds the activity words)
+        __builtin_amdgcn_s_sleep(2);
+    }
+    const unsigned long long e = (unsigned long long)planes | ((unsigned long long)unit << 16) | ho.tag_bits
+                               | ((unsigned long long)(pos & ASYNC_TAG_MASK) << 44) | ASYNC_ENTRY_VALID;
+    __hip_atomic_store(slot, e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#ifdef TTSWEEP_RING_DEBUG
+    atomicAdd(ho.ht + 25, 1ull);
+#endif
+}
+
+// Takes an idle unit whose pend word holds plane bits: pend -> ASYNC_BUSY.  `seen`: the word as last read (bits, no
+// busy bit).  Returns the plane bits taken, 0 when somebody else was faster.
+__device__ __forceinline__ unsigned handoff_take(unsigned *w, unsigned seen)
+{
+    for (int tries = 0; tries < 4 && seen != 0u && !(seen & ASYNC_BUSY); tries++) {
+        const unsigned prev = atomicCAS(w, seen, ASYNC_BUSY);
+        if (prev == seen) return seen;
+        seen = prev;        // (more bits have arrived, or the unit has been taken)
+    }
+    return 0u;
+}
+
+template <int NP, bool HO = false>
 __device__ __forceinline__ void push_improved(const DevLayout &L, int ra, int btiles, int cstrips,
                                               unsigned *__restrict__ pend, int a, int bt, int cs, int improved, int lane,
-                                              const DeferRule &rule, unsigned *__restrict__ defer)
+                                              const DeferRule &rule, unsigned *__restrict__ defer,
+                                              const HandOff &ho = HandOff{})
 {
     const int lo_num = a - ra - NP + 1;                                 // A' >= ceil(lo_num / NP)
     const int Alo = max(NP == 1 ? lo_num : (lo_num + 1) >> 1, 0);
@@ -873,7 +933,25 @@ __device__ __forceinline__ void push_improved(const DevLayout &L, int ra, int bt
             const float tda = (float)(NP * A - rule.sa) + 0.5f * (NP - 1), tdb = (float)(nb * STRIP_TB - rule.sb) + half_b,
                         tdc = (float)(nc * STRIP_K - rule.sc) + 0.5f * STRIP_K;
             const bool later = tda * tda + tdb * tdb + tdc * tdc < lim2;
-            atomicOr(&(later ? defer : pend)[(A * btiles + nb) * cstrips + nc], 1u << (a - (NP * A - ra)));
+            const int unit = (A * btiles + nb) * cstrips + nc;
+            const unsigned bit = 1u << (a - (NP * A - ra));
+            if (HO && !later && (ho.on & ASYNC_HANDOFF_NEIGHBOURS)) {
+                // the unit hears of it AND, when it is idle and inside the gate, goes into the ring at once
+                const unsigned old = atomicOr(&pend[unit], bit);
+                if (!(old & ASYNC_BUSY)) {
+                    // (the planner's distance: from the start to the nearest cell of the unit)
+                    const int a0 = NP * A, b0 = nb * STRIP_TB, c0 = nc * STRIP_K, tb_eff = min(STRIP_TB, L.n[1]);
+                    const float ga = (float)max(max(a0 - rule.sa, rule.sa - (a0 + NP - 1)), 0);
+                    const float gb = (float)max(max(b0 - rule.sb, rule.sb - (b0 + tb_eff - 1)), 0);
+                    const float gc = (float)max(max(c0 - rule.sc, rule.sc - (c0 + STRIP_K - 1)), 0);
+                    if (ga * ga + gb * gb + gc * gc <= ho.gate_r2) {
+                        const unsigned planes = handoff_take(&pend[unit], old | bit);
+                        if (planes) handoff_publish(ho, (unsigned)unit, planes);
+                    }
+                }
+            } else {
+                atomicOr(&(later ? defer : pend)[unit], bit);
+            }
         }
     }
 }
@@ -1042,7 +1120,8 @@ __device__ __forceinline__ void relax_special_cell(const DevLayout &L, const flo
                                                    const StartDesc &sd, int s, int cell,
                                                    int *__restrict__ changed,
                                                    const CellEntry *__restrict__ entries,
-                                                   int nentries, int ra, int np, int lane, float defer_margin)
+                                                   int nentries, int ra, int np, int lane, float defer_margin,
+                                                   const HandOff &ho = HandOff{})
 {
     const int ea = sd.box_hi[0] - sd.box_lo[0] + 1;
     const int eb = sd.box_hi[1] - sd.box_lo[1] + 1;
@@ -1097,8 +1176,8 @@ __device__ __forceinline__ void relax_special_cell(const DevLayout &L, const flo
         unsigned *const pend = reinterpret_cast<unsigned *>(sd.tile_flags + 2 * strip_flag_words(L));
         const DeferRule rule{sd.sa, sd.sb, sd.sc, defer_margin};
         unsigned *const defer = reinterpret_cast<unsigned *>(sd.tile_flags);
-        if (np == 1) push_improved<1>(L, ra, btiles, cstrips, pend, a, b / STRIP_TB, c / STRIP_K, FLAG_ALL, lane, rule, defer);
-        else push_improved<2>(L, ra, btiles, cstrips, pend, a, b / STRIP_TB, c / STRIP_K, FLAG_ALL, lane, rule, defer);
+        if (np == 1) push_improved<1, ASYNC>(L, ra, btiles, cstrips, pend, a, b / STRIP_TB, c / STRIP_K, FLAG_ALL, lane, rule, defer, ho);
+        else push_improved<2, ASYNC>(L, ra, btiles, cstrips, pend, a, b / STRIP_TB, c / STRIP_K, FLAG_ALL, lane, rule, defer, ho);
     }
 }
 
@@ -1124,14 +1203,16 @@ __device__ __forceinline__ buf_rsrc make_rsrc(const float *base)
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(base), 0, 0xffffffff, 0x00020000);
 }
 
+template <int NS>
 __device__ __forceinline__ void stage_slab(const float *__restrict__ v_slab, const float *__restrict__ t_slab,
                                            unsigned s1_bytes, float *slab, int rows, int rows8,
                                            int wave, int lane)
 {
+    static_assert(NS % 2 == 0, "a wave's 8-row groups have one parity");
     const buf_rsrc rv = make_rsrc(v_slab), rt = make_rsrc(t_slab);
     const int ninstr = rows8 / 8;           // wave-instructions per array
     const int rloc = lane >> 3, p = lane & 7;
-    // Wave w loads the 8-row groups kk = w, w + 4, ... of both arrays.  Row r = 8 kk + rloc
+    // Wave w loads the 8-row groups kk = w, w + NS, ... of both arrays.  Row r = 8 kk + rloc
     // has swizzle ((r >> 1) & 7) = (rloc >> 1) ^ (4 (kk & 1)), and kk & 1 = w & 1 for all of
     // a wave's groups, so one per-lane byte offset serves all its loads (but the slab's last
     // group, whose rows past the slab re-read its last row).
@@ -1141,31 +1222,31 @@ __device__ __forceinline__ void stage_slab(const float *__restrict__ v_slab, con
     const unsigned group_bytes = 8 * s1_bytes;
     unsigned soff = (unsigned)wave * group_bytes;
     float *dst = slab + wave * (8 * STRIP_W);                               // wave-uniform
-    for (int kk = wave; kk < ninstr; kk += STRIP_NS) {
+    for (int kk = wave; kk < ninstr; kk += NS) {
         const int vo = (int)(kk == ninstr - 1 ? voff_last : voff);
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rv, (__attribute__((address_space(3))) void *)dst,
                                                  16, vo, (int)soff, 0, 0);
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rt, (__attribute__((address_space(3))) void *)(dst + SLAB_T_BYTES / 4),
                                                  16, vo, (int)soff, 0, 0);
-        soff += STRIP_NS * group_bytes;
-        dst += STRIP_NS * 8 * STRIP_W;
+        soff += NS * group_bytes;
+        dst += NS * 8 * STRIP_W;
     }
 }
 
 // -DTTSWEEP_PROFILE: cycle counts of wave 0 per phase, summed over all units (tuning aid)
 #ifdef TTSWEEP_PROFILE
-__device__ unsigned long long g_prof[8];
+__device__ unsigned long long g_prof[10];
 #define PROF_T(x) const long long x = clock64()
 void prof_dump()
 {
-    unsigned long long h[8] = {};
+    unsigned long long h[10] = {};
     (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(g_prof), sizeof(h));
     const double n = (double)std::max<unsigned long long>(h[6], 1);
-    fprintf(stderr, "prof (wave 0, cycles per unit, %llu units): fetch %.0f  prologue %.0f  wait %.0f  stage %.0f  "
+    fprintf(stderr, "prof (wave 0, cycles per unit, %llu units): fetch %.0f  prologue %.0f  wait %.0f (of it for the loads %.0f, %.2f group boundaries)  stage %.0f  "
             "compute %.0f  epilogue %.0f  | busy / resident cycles of the workgroups: %.3f\n",
-            h[6], h[0] / n, h[1] / n, h[2] / n, h[3] / n, h[4] / n, h[5] / n,
+            h[6], h[0] / n, h[1] / n, h[2] / n, h[8] / n, h[9] / n, h[3] / n, h[4] / n, h[5] / n,
             (double)(h[0] + h[1] + h[2] + h[3] + h[4] + h[5]) / (double)std::max<unsigned long long>(h[7], 1));
-    unsigned long long z[8] = {};
+    unsigned long long z[10] = {};
     (void)hipMemcpyToSymbol(HIP_SYMBOL(g_prof), z, sizeof(z));
 }
 #else
@@ -1196,8 +1277,8 @@ __device__ __forceinline__ void async_fail(const AsyncSolve &as, unsigned code)
     atomicCAS(as.status, (unsigned)ASYNC_OK, code);
 }
 
-// Planner of ring r: all 256 threads of one workgroup.  `lds`: scratch words of its own.
-template <int NP>
+// Planner of ring r: all 64 NS threads of one workgroup.  `lds`: scratch words of its own.
+template <int NP, int NS>
 __device__ __forceinline__ void async_planner(const DevLayout &L, const StartDesc *__restrict__ starts, const AsyncSolve &as,
                                            const int r, const int btiles, const int cstrips, const int ra,
                                            const PlaneCounts &pc, int *__restrict__ flags0, const long long flags_stride,
@@ -1208,16 +1289,20 @@ __device__ __forceinline__ void async_planner(const DevLayout &L, const StartDes
     const int4 *__restrict__ list = as.list + as.ring_off[r];
     const int n = as.ring_len[r];
     unsigned long long *const ht = as.ctl + (size_t)r * ASYNC_CTL_STRIDE;
+    unsigned *const gate_word = reinterpret_cast<unsigned *>(ht + 8);
     unsigned *const completed = reinterpret_cast<unsigned *>(ht + 16);
     unsigned long long *const ents = as.entries + (size_t)r * (size_t)(as.cap_mask + 1);
     const int ns = as.ring_start_off[r + 1] - as.ring_start_off[r];
     const int *__restrict__ rstarts = as.ring_starts + as.ring_start_off[r];
     const int nflag = L.n[0] * btiles * cstrips;
+    const bool handoff = as.handoff != 0;       // workers publish too: positions are reserved with a returning add
     constexpr int KSCAN = 4;                    // list entries per thread and scan step
+    constexpr int NT = STRIP_TB * NS;           // threads of the workgroup
     int *sh = lds;                              // [0] head, [1] completed, [2] stop, [3] dead-edge entries just published,
-                                                // [4] first list position this round met with anything to do
+                                                // [4] first list position this round met with anything to do,
+                                                // [5] first position of a reservation, [6] tail
     int *cnt = lds + 8;                         // [KSCAN][waves] due units found
-    int *dirty = lds + 8 + KSCAN * STRIP_NS;    // [ASYNC_RING_STARTS] units published since the start's last special
+    int *dirty = lds + 8 + KSCAN * NS;    // [ASYNC_RING_STARTS] units published since the start's last special
     int *minact = dirty + ASYNC_RING_STARTS;    // [ASYNC_RING_STARTS] smallest squared distance (float bits) met with work, this round
     float *gate2 = reinterpret_cast<float *>(minact + ASYNC_RING_STARTS);      // [ASYNC_RING_STARTS] squared gate radius per start
     // (the gate is for boxes that grow from ONE source patch - what the initialisation counted -: a box
@@ -1231,7 +1316,8 @@ __device__ __forceinline__ void async_planner(const DevLayout &L, const StartDes
         gate2[tid] = 3.0e38f;
     }
     __syncthreads();
-    unsigned t = 0;                             // entries published so far (uniform)
+    unsigned t = 0;                             // entries published so far (uniform; with hand-off: as last read)
+    unsigned t_special = 0xffffffffu;           // (hand-off) the tail right after the dead-edge cells' last turn at rest
     const long long clock0 = wall_clock64();
     // state of the scan in progress (uniform but `activity`): where it continues, which round it belongs to,
     // whether the ring was at rest when it began, whether it met a word that was not zero
@@ -1243,52 +1329,94 @@ __device__ __forceinline__ void async_planner(const DevLayout &L, const StartDes
     unsigned long long nodefer = 0ull;
     float gate_r2 = 3.0e38f, gate_r = as.gate_r0;
 
+    // an entry goes into its slot when the slot is empty: it is, unless the ring has been lapped while a worker sat
+    // on the entry that was there (ttsweep_dev.h, ring entry)
+    auto store_entry = [&](unsigned long long *slot, unsigned long long e) {
+        for (unsigned spin = 0; slot_load(slot) != 0ull; spin++) {
+            if ((spin & 63u) == 63u && (ald32(as.status) != ASYNC_OK || wall_clock64() - clock0 > as.timeout_ticks)) break;
+            __builtin_amdgcn_s_sleep(2);
+        }
+        __hip_atomic_store(slot, e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#ifdef TTSWEEP_RING_DEBUG
+        atomicAdd(ht + 24, 1ull);
+#endif
+    };
+    // positions of `total` entries (uniform; every thread calls): without hand-off the planner is the ring's only
+    // producer - the positions follow its own count and the tail moves when the entries are in memory (commit); with
+    // hand-off they are reserved at once (a worker that claims one before its entry has arrived waits at the slot)
+    auto reserve = [&](int total) -> unsigned {
+        if (!handoff) return t;
+        if (tid == 0) sh[5] = total ? (int)((unsigned)(atomicAdd(ht, (unsigned long long)total << 32) >> 32) & 0x7fffffffu) : (int)t;
+#ifdef TTSWEEP_RING_DEBUG
+        if (tid == 0 && total) atomicAdd(ht + 28, (unsigned long long)total);
+        if (tid == 0 && total < 0) atomicAdd(ht + 29, 1ull);
+#endif
+        __syncthreads();
+        const unsigned b = (unsigned)sh[5];
+        __syncthreads();
+        return b;
+    };
+    auto commit = [&](unsigned first, int total) {
+        if (!handoff) {
+            // the entries are in memory before the tail says so
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (tid == 0 && total) atomicAdd(ht, (unsigned long long)total << 32);
+        }
+        t = first + (unsigned)total;
+    };
+
     // publishes the dead-edge entries of the ring's starts whose counter has reached `threshold`
     auto publish_specials = [&](int threshold) -> int {
-        int total = 0;
-        if (wave == 0) {
-            const bool need = lane < ns && dirty[lane] >= threshold;
-            const unsigned long long bal = __ballot(need);
-            if (need) {
-                const unsigned pos = t + (unsigned)__popcll(bal & ((1ull << lane) - 1ull));
-                const unsigned long long e = 0xffffull | ((unsigned long long)ASYNC_UNIT_SPECIAL << 16)
-                                           | ((unsigned long long)rstarts[lane] << 36)
-                                           | ((unsigned long long)(pos & 0x7ffffu) << 44) | nodefer;
-                __hip_atomic_store(ents + (pos & (unsigned)as.cap_mask), e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                dirty[lane] = 0;
-            }
-            total = __popcll(bal);
-            if (lane == 0) sh[3] = total;
-        }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        // (the counters are what the scan's last step left: every wave has added its share - with hand-off nothing
+        // else stands between those adds and this read; and who is due is decided ONCE: a counter that reached the
+        // threshold between a count and a second look would get an entry at a position nobody reserved)
         __syncthreads();
-        total = sh[3];
-        if (tid == 0 && total) atomicAdd(ht, (unsigned long long)total << 32);
+        bool need = false;
+        unsigned long long bal = 0ull;
+        if (wave == 0) {
+            need = lane < ns && dirty[lane] >= threshold;
+            bal = __ballot(need);
+            if (lane == 0) sh[3] = __popcll(bal);
+        }
+        __syncthreads();
+        const int total = sh[3];
+        __syncthreads();
+        const unsigned first = reserve(total);
+        if (wave == 0 && need) {
+            const unsigned pos = first + (unsigned)__popcll(bal & ((1ull << lane) - 1ull));
+            const unsigned long long e = 0xffffull | ((unsigned long long)ASYNC_UNIT_SPECIAL << 16)
+                                       | ((unsigned long long)rstarts[lane] << 36)
+                                       | ((unsigned long long)(pos & ASYNC_TAG_MASK) << 44) | ASYNC_ENTRY_VALID | nodefer;
+            store_entry(ents + (pos & (unsigned)as.cap_mask), e);
+            dirty[lane] = 0;
+        }
+        commit(first, total);
         __syncthreads();
         return total;
     };
 
     for (;;) {
-        // ---- wait until the ring has room (and its slots have been read: published - completed
-        // stays well below the capacity).  `completed` counts finished entries, not a prefix of them: a worker that
-        // has claimed position j and is held up between its claim and its first look at the slot for as long as the
-        // others need for a whole lap of the ring (16 384 units, a millisecond and more of everybody else's work -
-        // only a pre-empted wavefront is) finds the slot published again for j + capacity, waits for a tag that never
-        // comes, and the unit it should have relaxed stays busy: the solve then ends at its wall-clock limit, the pass
-        // driver finishes it from the boxes as they are, and ttsweep_stats.fallbacks says so.  A worker whose claim
-        // lands beyond the tail waits at this ring for the planner's next entries or its done bit (async_claim).
+        // ---- wait until the ring has room.  (A slot is never written before the entry it held has been read - see
+        // store_entry -, so the bound on published - completed is a throttle, not what keeps the ring consistent.)
         unsigned h, c;
         for (;;) {
             if (tid == 0) {
-                sh[0] = (int)(unsigned)ald64(ht);
+                // completed first, then the tail: completed(then) == tail(now) means nothing is queued or running now
+                // (with hand-off a running worker may publish; both counts only grow, completed never beyond the tail)
                 sh[1] = (int)ald32(completed);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                const unsigned long long x = ald64(ht);
+                sh[0] = (int)(unsigned)x;
+                sh[6] = (int)((unsigned)(x >> 32) & 0x7fffffffu);
                 int stop = ald32(as.status) != ASYNC_OK;
                 if (!stop && wall_clock64() - clock0 > as.timeout_ticks) { async_fail(as, ASYNC_ERR_TIMEOUT); stop = 1; }
-                if (!stop && (long long)t > as.max_entries) { async_fail(as, ASYNC_ERR_CAP); stop = 1; }
+                if (!stop && (long long)(handoff ? (unsigned)sh[6] : t) > as.max_entries) { async_fail(as, ASYNC_ERR_CAP); stop = 1; }
                 sh[2] = stop;
             }
             __syncthreads();
             h = (unsigned)sh[0]; c = (unsigned)sh[1];
+            if (handoff) t = (unsigned)sh[6];
             const int stop = sh[2];
             __syncthreads();
             if (stop) {         // give up: the workers see the status word and leave
@@ -1310,7 +1438,7 @@ __device__ __forceinline__ void async_planner(const DevLayout &L, const StartDes
             __syncthreads();
             if (tid == 0) sh[4] = 0x7fffffff;
             base = 0;
-            if (as.policy != 0 && fa < n && (round & 15) != 0) base = max(fa - as.scan_slack, 0) / (KSCAN * 256) * (KSCAN * 256);
+            if (as.policy != 0 && fa < n && (round & 15) != 0) base = max(fa - as.scan_slack, 0) / (KSCAN * NT) * (KSCAN * NT);
             from_zero = base == 0;
             quiet = c == t;                     // nothing queued, nothing running: the scan sees a still picture
             activity = 0;
@@ -1319,6 +1447,8 @@ __device__ __forceinline__ void async_planner(const DevLayout &L, const StartDes
             // cannot fill the machine from behind a slow gate, many starts waste work behind a fast one
             if (round > 0) gate_r += (int)(t - h) <= 0 ? as.gate_fast : as.gate_speed;
             gate_r2 = as.policy == 1 && as.gate_speed > 0.f ? gate_r * gate_r : 3.0e38f;
+            // (the workers that hand units on keep inside the same gate)
+            if (handoff && tid == 0) __hip_atomic_store(gate_word, __float_as_uint(gate_r2), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (as.policy == 2) {
                 // window: a start's units are handed out up to `window` cells beyond the nearest unit
                 // the previous round met with anything to do (everything, if it met none)
@@ -1332,7 +1462,7 @@ __device__ __forceinline__ void async_planner(const DevLayout &L, const StartDes
                 __syncthreads();
             }
         }
-        for (; base < n; base += KSCAN * 256) {
+        for (; base < n; base += KSCAN * NT) {
             if ((int)(t - h) >= as.high) break;
             int ss[KSCAN], uu[KSCAN], dd[KSCAN];
             unsigned w[KSCAN], planes[KSCAN];
@@ -1340,7 +1470,7 @@ __device__ __forceinline__ void async_planner(const DevLayout &L, const StartDes
             int open_any = 0;
 #pragma unroll
             for (int k = 0; k < KSCAN; k++) {
-                const int idx = base + k * 256 + tid;
+                const int idx = base + k * NT + tid;
                 int4 it = make_int4(0, -1, 0, 0);
                 if (idx < n) it = list[idx];
                 if (gated[it.x >> 16] && __int_as_float(it.z) > (as.policy == 2 ? gate2[it.x >> 16] : gate_r2)) {   // behind the gate: not even looked at (the round ends
@@ -1370,8 +1500,11 @@ __device__ __forceinline__ void async_planner(const DevLayout &L, const StartDes
                 if (w[k] != 0u) {
                     activity = 1;
                     if (as.policy == 2) atomicMin(&minact[ss[k] >> 16], dd[k]);
-                    // only the planner sets the busy bit: a word seen without it holds plane bits alone
-                    if (!(w[k] & ASYNC_BUSY)) planes[k] = atomicExch(pw[k], ASYNC_BUSY) & ~ASYNC_BUSY;
+                    // without hand-off only the planner sets the busy bit: a word seen without it holds plane bits
+                    // alone and stays that way until the exchange; with hand-off a worker may take the unit in
+                    // between: compare-and-swap, the loser leaves the bits where they are
+                    if (!(w[k] & ASYNC_BUSY))
+                        planes[k] = handoff ? handoff_take(pw[k], w[k]) : atomicExch(pw[k], ASYNC_BUSY) & ~ASYNC_BUSY;
                 }
             }
             int rank[KSCAN];
@@ -1379,70 +1512,78 @@ __device__ __forceinline__ void async_planner(const DevLayout &L, const StartDes
             for (int k = 0; k < KSCAN; k++) {
                 const unsigned long long bal = __ballot(planes[k] != 0u);
                 rank[k] = __popcll(bal & ((1ull << lane) - 1ull));
-                if (lane == 0) cnt[k * STRIP_NS + wave] = __popcll(bal);
+                if (lane == 0) cnt[k * NS + wave] = __popcll(bal);
             }
             __syncthreads();
             int total = 0, off[KSCAN];
 #pragma unroll
             for (int k = 0; k < KSCAN; k++) {
 #pragma unroll
-                for (int ww = 0; ww < STRIP_NS; ww++) {
+                for (int ww = 0; ww < NS; ww++) {
                     if (ww == wave) off[k] = total;
-                    total += cnt[k * STRIP_NS + ww];
+                    total += cnt[k * NS + ww];
                 }
             }
+            const unsigned first = reserve(total);
 #pragma unroll
             for (int k = 0; k < KSCAN; k++) {
                 unsigned long long relax = 0;
                 const int s = ss[k] & 0xffff;
                 if (planes[k] != 0u) {
-                    const unsigned pos = t + (unsigned)(off[k] + rank[k]);
+                    const unsigned pos = first + (unsigned)(off[k] + rank[k]);
                     const unsigned long long e = (unsigned long long)planes[k] | ((unsigned long long)(unsigned)uu[k] << 16)
-                                               | ((unsigned long long)s << 36) | ((unsigned long long)(pos & 0x7ffffu) << 44) | nodefer;
-                    __hip_atomic_store(ents + (pos & (unsigned)as.cap_mask), e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                               | ((unsigned long long)s << 36) | ((unsigned long long)(pos & ASYNC_TAG_MASK) << 44)
+                                               | ASYNC_ENTRY_VALID | nodefer;
+                    store_entry(ents + (pos & (unsigned)as.cap_mask), e);
                     atomicAdd(&dirty[ss[k] >> 16], 1);
-                    int u = uu[k];
-                    const int cs = u % cstrips;  u /= cstrips;
-                    const int bt = u % btiles;   u /= btiles;
-                    const int wb = min(min(STRIP_TB, L.n[1]), L.n[1] - bt * STRIP_TB), wc = max(min(STRIP_K, L.n[2] - cs * STRIP_K), 0);
-                    const bool two = NP > 1 && NP * u + 1 < L.n[0];
-                    int nent = 0;
-                    for (int p = 0; p < 2 * ra + NP; p++)
-                        if ((planes[k] >> p) & 1u) nent += pc.n[p][0] + (two ? pc.n[p][1] : 0);
-                    relax = (unsigned long long)(wb * wc) * (unsigned long long)nent;
+                    if (!handoff) {
+                        int u = uu[k];
+                        const int cs = u % cstrips;  u /= cstrips;
+                        const int bt = u % btiles;   u /= btiles;
+                        const int wb = min(min(STRIP_TB, L.n[1]), L.n[1] - bt * STRIP_TB), wc = max(min(STRIP_K, L.n[2] - cs * STRIP_K), 0);
+                        const bool two = NP > 1 && NP * u + 1 < L.n[0];
+                        int nent = 0;
+                        for (int p = 0; p < 2 * ra + NP; p++)
+                            if ((planes[k] >> p) & 1u) nent += pc.n[p][0] + (two ? pc.n[p][1] : 0);
+                        relax = (unsigned long long)(wb * wc) * (unsigned long long)nent;
+                    }
                 }
-                // the starts' work counters: one pair of atomics per wavefront and start
-                unsigned long long rest = __ballot(planes[k] != 0u);
+                // the starts' work counters: one pair of atomics per wavefront and start (with hand-off the workers
+                // count what they relax themselves: the planner does not see every entry)
+                unsigned long long rest = handoff ? 0ull : __ballot(planes[k] != 0u);
                 while (rest) {
-                    const int first = __builtin_ctzll(rest);
-                    const int s0 = __shfl(s, first);
+                    const int first_lane = __builtin_ctzll(rest);
+                    const int s0 = __shfl(s, first_lane);
                     const bool mine = planes[k] != 0u && s == s0;
                     const unsigned long long mm = __ballot(mine);
                     unsigned long long sum = mine ? relax : 0ull;
 #pragma unroll
                     for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
-                    if (lane == first) {
+                    if (lane == first_lane) {
                         atomicAdd(starts[s0].work, sum);
                         atomicAdd(starts[s0].work + 2, (unsigned long long)__popcll(mm));
                     }
                     rest &= ~mm;
                 }
             }
-            // the entries are in memory before the tail says so
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
-            if (tid == 0 && total) atomicAdd(ht, (unsigned long long)total << 32);
-            t += (unsigned)total;
+            commit(first, total);
         }
         const bool whole = base >= n;
         if (whole) activity = __syncthreads_or(activity);
         if (whole && !activity && quiet && from_zero) {
-            // the ring is at rest; the dead-edge cells once more if units ran since their last turn
+            // the ring is at rest; the dead-edge cells once more if units ran since their last turn (with hand-off
+            // the planner has not seen every unit: whatever was published since that turn counts for every start)
+            if (handoff && t != t_special) {
+                __syncthreads();
+                if (tid < ns) dirty[tid] = max(dirty[tid], 1);
+                __syncthreads();
+            }
             const int sp = publish_specials(1);
+            if (handoff) t_special = t;         // (their own entries included)
             if (sp == 0) {
                 // really at rest: the deferred bits (push_improved) become pend bits; none: done
                 int moved = 0;
-                for (int idx = tid; idx < n; idx += 256) {
+                for (int idx = tid; idx < n; idx += NT) {
                     const int4 it = list[idx];
                     if (it.y < 0) continue;
                     unsigned *const df = reinterpret_cast<unsigned *>(flags0 + (long long)(it.x & 0xffff) * flags_stride) + it.y;
@@ -1456,9 +1597,8 @@ __device__ __forceinline__ void async_planner(const DevLayout &L, const StartDes
                 }
                 nodefer = 1ull << 63;
             }
-            t += (unsigned)sp;
         } else {
-            t += (unsigned)publish_specials(as.special_every);
+            (void)publish_specials(as.special_every);
         }
     }
 }
@@ -1478,8 +1618,16 @@ __device__ __forceinline__ unsigned long long async_claim(const AsyncSolve &as, 
                 const unsigned j = (unsigned)atomicAdd(ht, 1ull);
                 const unsigned long long *slot = as.entries + (size_t)q * (size_t)(as.cap_mask + 1) + (j & (unsigned)as.cap_mask);
                 for (unsigned spin2 = 0;; spin2++) {
-                    const unsigned long long e = ald64(slot);
-                    if (((unsigned)(e >> 44) & 0x7ffffu) == (j & 0x7ffffu)) { *ring = q; return e; }
+                    const unsigned long long e = slot_load(slot);
+                    if ((e & ASYNC_ENTRY_VALID) && ((unsigned)(e >> 44) & ASYNC_TAG_MASK) == (j & ASYNC_TAG_MASK)) {
+                        // read: the slot is free for the position one lap on
+                        __hip_atomic_store(const_cast<unsigned long long *>(slot), 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#ifdef TTSWEEP_RING_DEBUG
+                        atomicAdd(ht + 26, 1ull);
+#endif
+                        *ring = q;
+                        return e;
+                    }
                     // not published (yet): somebody else was faster and position j lies beyond the tail
                     const unsigned long long y = ald64(ht);
                     if ((y >> 63) && (int)(j - ((unsigned)(y >> 32) & 0x7fffffffu)) >= 0) break;   // ... and never will be
@@ -1502,15 +1650,26 @@ __device__ __forceinline__ unsigned long long async_claim(const AsyncSolve &as, 
     }
 }
 
-template <int K, int NP, bool ASYNC>
-__global__ void __launch_bounds__(STRIP_TB *STRIP_NS, TTSWEEP_WGS_PER_CU)
+// NS waves per workgroup split the items of a staged plane (the plan's NS shares); G staged planes per GROUP: the
+// slabs of a group are asked for together, waited for together (one vmcnt(0) + barrier per group) and relaxed one
+// after the other while the next group loads into the other half of the 2 G slabs.
+// Throughput instances: NS = 4, two workgroups per CU, G = 1 (a plane at a time: 40 KB of slabs per workgroup).
+// Latency instance (small shards, one-plane units): NS = 8, ONE workgroup per CU - a unit is relaxed by all eight
+// waves of a CU at once: a wave does half the arithmetic (compute 45.5 k -> 20-23 k cycles per unit) -, G = 3: eight
+// waves split a plane's ten or so items unevenly (the longest share of a plane is 1.3 times the mean, 1.1 with four
+// waves) and meet at a barrier twice as often per unit of work; with three planes between two barriers - the shares
+// rotated from plane to plane - a unit's waves wait 10 k instead of 17 k cycles, and a group's compute covers the load
+// latency of the next (profiles/r05_lat_*.txt; two teams of four waves with half a strip each - the balance of four
+// shares, three quarters of the LDS reads for half of the relaxations - came out slower: r05_lat_teams_*.txt).
+template <int K, int NP, bool ASYNC, int NS, int G>
+__global__ void __launch_bounds__(STRIP_TB *NS, (NS == STRIP_NS ? TTSWEEP_WGS_PER_CU : 1))
 sweep_units_kernel(DevLayout L, const float *__restrict__ v, const StartDesc *__restrict__ starts,
                    const int4 *__restrict__ lists, int list_cap, int nlists, int *__restrict__ ctrl,
                    int *__restrict__ changed, const StripItem *__restrict__ items, StripPlan plan,
                    int btiles, int cstrips, UnitPassTail tail, AsyncSolve as, PlaneCounts pc,
                    int *__restrict__ flags0, long long flags_stride)
 {
-    constexpr int NS = STRIP_NS;
+    constexpr int STRIP_LDS_HEAD = strip_lds_head(NS);
     constexpr int W = K + 2 * STRIP_CF;
     static_assert(K == STRIP_K && STRIP_W == 32 && W == 32, "slab rows are 8 float4 wide");
     static_assert(NP >= 1 && NP <= STRIP_PLANES && (NP * K) % NS == 0 && K % (NP * K / NS) == 0,
@@ -1528,7 +1687,7 @@ sweep_units_kernel(DevLayout L, const float *__restrict__ v, const StartDesc *__
     const int rows8 = (rows + 7) & ~7;
     constexpr int slab_floats = SLAB_BYTES / 4;     // v rows, then T rows
     const int nflag = L.n[0] * btiles * cstrips;
-    float *slabs = smem + STRIP_LDS_HEAD;           // two slabs (double buffer)
+    float *slabs = smem + STRIP_LDS_HEAD;           // 2 G slabs: two groups of G staged planes
     float *comb = smem + STRIP_LDS_HEAD;            // [wave][plane][cell][lane], aliases the slabs
     const int nitems = plan.first[plan.nstaged];
     unsigned plane_mask = 0;                        // staged planes that have items at all
@@ -1540,8 +1699,11 @@ sweep_units_kernel(DevLayout L, const float *__restrict__ v, const StartDesc *__
     if (tid < NS * 16) {
         const int w = tid >> 4, p = tid & 15;
         int packed = 0;
+        // (G > 1: the shares of a plane are dealt to the waves rotated by the plane's index - the longest share of
+        // every plane would otherwise go to wave 0, and a group's waits are for the SUM over its planes)
+        const int sh = G > 1 ? (w + p) % NS : w;
         if (p < plan.nstaged)
-            packed = (plan.first[p] + plan.wsplit[p][w]) | ((plan.first[p] + plan.wsplit[p][w + 1]) << 16);
+            packed = (plan.first[p] + plan.wsplit[p][sh]) | ((plan.first[p] + plan.wsplit[p][sh + 1]) << 16);
         item_range[tid] = packed;
     }
     // the queue lengths are final when this kernel starts (the planner wrote them): read them
@@ -1557,7 +1719,7 @@ sweep_units_kernel(DevLayout L, const float *__restrict__ v, const StartDesc *__
     if (ASYNC) {
         // one launch per solve: the first workgroups plan (one ring each), the others work
         if ((int)blockIdx.x < as.nrings) {
-            async_planner<NP>(L, starts, as, (int)blockIdx.x, btiles, cstrips, plan.ra, pc, flags0, flags_stride,
+            async_planner<NP, NS>(L, starts, as, (int)blockIdx.x, btiles, cstrips, plan.ra, pc, flags0, flags_stride,
                               reinterpret_cast<int *>(smem) + STRIP_LDS_HEAD);
             return;
         }
@@ -1582,12 +1744,30 @@ sweep_units_kernel(DevLayout L, const float *__restrict__ v, const StartDesc *__
     int flagged = -1;           // (lane 0 of a wave) the start whose "improved" bit this wave has set
     // (thread 0) relaxations of the in-unit passes, summed until the workgroup turns to another start: the planner
     // counts what it hands out, these it does not see
-    unsigned long long extra_relax = 0;
+    unsigned long long extra_relax = 0, extra_units = 0;
     int extra_s = -1;
     const long long async_clock0 = ASYNC ? wall_clock64() : 0;
 #ifdef TTSWEEP_PROFILE
-    unsigned long long prof_acc[7] = {};
+    unsigned long long prof_acc[7] = {}, prof_vm = 0, prof_groups = 0;
 #endif
+    // (hand-off: made where it is used - at the end of a unit -, so that nothing of it lives through the relaxation)
+    auto make_handoff = [&](int s, int q, float defer_margin) -> HandOff {
+        HandOff ho{};
+        if (ASYNC && as.handoff) {
+            // a start that does not grow from one source patch is relaxed ungated (async_planner: gated[])
+            const bool gated = __builtin_amdgcn_readfirstlane(flags0[(long long)s * flags_stride + 3 * nflag]) == 1;
+            ho.on = as.handoff;
+            ho.gate_r2 = gated ? __uint_as_float((unsigned)__builtin_amdgcn_readfirstlane(head[3])) : 3.0e38f;
+            ho.ht = as.ctl + (size_t)q * ASYNC_CTL_STRIDE;
+            ho.ents = as.entries + (size_t)q * (size_t)(as.cap_mask + 1);
+            ho.cap_mask = (unsigned)as.cap_mask;
+            // ("tell every unit at once": the entries after the ring's first flush - or no deferral at all)
+            ho.tag_bits = ((unsigned long long)s << 36) | (defer_margin < -1.0e30f ? 1ull << 63 : 0ull);
+            ho.status = as.status;
+            ho.deadline = async_clock0 + as.timeout_ticks;
+        }
+        return ho;
+    };
     while (ASYNC || probe < nlists) {
         // ---- take the next unit of queue q (every wave leaves through the same exit:
         // all queues exhausted)
@@ -1601,11 +1781,16 @@ sweep_units_kernel(DevLayout L, const float *__restrict__ v, const StartDesc *__
             if (tid == 0) {
                 int ring = 0;
                 const unsigned long long e = async_claim(as, home, &ring, async_clock0);
+                // (hand-off: the gate of the ring's planner, as it stands now - it only ever opens)
+                unsigned gate_bits = 0u;
+                if (as.handoff) gate_bits = ald32(reinterpret_cast<const unsigned *>(as.ctl + (size_t)ring * ASYNC_CTL_STRIDE + 8));
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 head[0] = (int)(unsigned)e;
                 head[1] = (int)(unsigned)(e >> 32);
                 head[2] = ring;
+                head[3] = (int)gate_bits;
+                head[4] = 0; head[5] = 0;       // (hand-off: what the waves improved, per own plane)
             }
             __syncthreads();
             const unsigned e_lo = (unsigned)__builtin_amdgcn_readfirstlane(head[0]);
@@ -1619,8 +1804,9 @@ sweep_units_kernel(DevLayout L, const float *__restrict__ v, const StartDesc *__
             if ((unsigned)my_unit == ASYNC_UNIT_SPECIAL) {
                 // the dead-edge cells of start s, one wave per cell
                 const StartDesc sd = starts[s];
+                const HandOff ho = make_handoff(s, q, defer_margin);
                 for (int cell = wave; cell < tail.max_box_cells; cell += NS)
-                    relax_special_cell<true>(L, v, sd, s, cell, changed, tail.entries, tail.nentries, plan.ra, NP, lane, defer_margin);
+                    relax_special_cell<true>(L, v, sd, s, cell, changed, tail.entries, tail.nentries, plan.ra, NP, lane, defer_margin, ho);
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 __syncthreads();
                 if (tid == 0) atomicAdd(reinterpret_cast<unsigned *>(as.ctl + (size_t)q * ASYNC_CTL_STRIDE + 16), 1u);
@@ -1648,7 +1834,7 @@ sweep_units_kernel(DevLayout L, const float *__restrict__ v, const StartDesc *__
         }
         PROF_T(t_fetch);
 #ifdef TTSWEEP_PROFILE
-        long long p_wait = 0, p_stage = 0, p_comp = 0;
+        long long p_wait = 0, p_stage = 0, p_comp = 0, p_vm = 0, p_groups = 0;
 #endif
         int u = my_unit;
         const int cs = u % cstrips;  u /= cstrips;
@@ -1670,11 +1856,22 @@ sweep_units_kernel(DevLayout L, const float *__restrict__ v, const StartDesc *__
         const long long src0 = (long long)(a0 - plan.ra + L.lo[0]) * L.s0
                              + (long long)(b0 - rb + L.lo[1]) * L.s1 + (c0 - STRIP_CF + L.lo[2]);
         const unsigned s1_bytes = (unsigned)(L.s1 * 4);
-        int buf = 0;
-        if (todo) {
-            const long long src = src0 + (long long)__builtin_ctz(todo) * L.s0;
-            stage_slab(v + src, T + src, s1_bytes, slabs, rows, rows8, wave, lane);
-        }
+        // Groups of G staged planes: `unissued` are the planes whose slabs have not been asked for yet (always the
+        // groups behind the one being relaxed), `half` the half of the slabs the group being relaxed lies in,
+        // `in_group` the plane's position in its group.
+        unsigned unissued = todo;
+        int half = 0, in_group = 0;
+        auto issue_group = [&](int into_half) {
+#pragma unroll
+            for (int i = 0; i < G; i++) {
+                if (unissued) {
+                    const long long src = src0 + (long long)__builtin_ctz(unissued) * L.s0;
+                    stage_slab<NS>(v + src, T + src, s1_bytes, slabs + (into_half * G + i) * slab_floats, rows, rows8, wave, lane);
+                    unissued &= unissued - 1;
+                }
+            }
+        };
+        issue_group(0);
         // header of the first item this wave will relax (later ones are requested one item
         // ahead, across plane boundaries)
         ItemHdr cur = load_hdr(items, min(__builtin_amdgcn_readfirstlane(
@@ -1707,8 +1904,10 @@ sweep_units_kernel(DevLayout L, const float *__restrict__ v, const StartDesc *__
 #pragma unroll
         for (int qq = 0; qq < CQ; qq++) {   // (wave-uniform selects between compile-time registers)
 #define ACC_FLAT(e) acc[(e) / K][(e) % K]
-            told[qq] = wave == 0 ? ACC_FLAT(qq) : wave == 1 ? ACC_FLAT(CQ + qq)
-                     : wave == 2 ? ACC_FLAT(2 * CQ + qq) : ACC_FLAT(3 * CQ + qq);
+            float tv = ACC_FLAT(qq);
+#pragma unroll
+            for (int w = 1; w < NS; w++) tv = wave == w ? ACC_FLAT(w * CQ + qq) : tv;
+            told[qq] = tv;
 #undef ACC_FLAT
         }
 
@@ -1724,22 +1923,24 @@ sweep_units_kernel(DevLayout L, const float *__restrict__ v, const StartDesc *__
             const int next_first = todo
                 ? min(__builtin_amdgcn_readfirstlane(item_range[wave * 16 + __builtin_ctz(todo)]) & 0xffff, nitems - 1)
                 : 0;
-            // this wave's part of slab `p` has landed ...
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            // ... and so has everybody else's; the other slab is no longer read
-            __syncthreads();
-            PROF_T(t1);
-            // the next plane loads into the other slab while this one is relaxed
-            if (todo) {
-                const long long src = src0 + (long long)__builtin_ctz(todo) * L.s0;
-                stage_slab(v + src, T + src, s1_bytes, slabs + (buf ^ 1) * slab_floats, rows, rows8, wave, lane);
+            if (in_group == 0) {
+                // a group begins: this wave's part of its slabs has landed ...
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#ifdef TTSWEEP_PROFILE
+                p_vm += clock64() - t0; p_groups++;
+#endif
+                // ... and so has everybody else's; the other half of the slabs is no longer read
+                __syncthreads();
             }
+            PROF_T(t1);
+            // the next group loads into the other half while this one is relaxed
+            if (in_group == 0) issue_group(half ^ 1);
             PROF_T(t2);
 #ifdef TTSWEEP_PROFILE
             p_wait += t1 - t0; p_stage += t2 - t1;
 #endif
 
-            const float *sv = slabs + buf * slab_floats;
+            const float *sv = slabs + (half * G + in_group) * slab_floats;
             for (int ii = ibeg; ii < iend; ii++) {
                 const const_item_ptr item = (const_item_ptr)(items + ii);
                 // this item's offset lengths and the next item's header travel while the
@@ -1769,7 +1970,7 @@ sweep_units_kernel(DevLayout L, const float *__restrict__ v, const StartDesc *__
                 cur = nxt;
             }
             if (ibeg >= iend) cur = load_hdr(items, next_first);    // (no item of this plane was ours)
-            buf ^= 1;
+            if (++in_group == G) { in_group = 0; half ^= 1; }
 #ifdef TTSWEEP_PROFILE
             p_comp += clock64() - t2;
 #endif
@@ -1832,11 +2033,9 @@ sweep_units_kernel(DevLayout L, const float *__restrict__ v, const StartDesc *__
         for (int qq = 0; qq < CQ; qq++) told[qq] = fminf(told[qq], best[qq]);
         todo = (((1u << NP) - 1u) << plan.ra) & plane_mask;
         inunit_passes++;
-        buf = 0;
-        if (todo) {
-            const long long src = src0 + (long long)__builtin_ctz(todo) * L.s0;
-            stage_slab(v + src, T + src, s1_bytes, slabs, rows, rows8, wave, lane);
-        }
+        unissued = todo;
+        half = 0; in_group = 0;
+        issue_group(0);
         cur = load_hdr(items, min(__builtin_amdgcn_readfirstlane(
             item_range[wave * 16 + (todo ? __builtin_ctz(todo) : 0)]) & 0xffff, nitems - 1));
         }
@@ -1846,7 +2045,9 @@ sweep_units_kernel(DevLayout L, const float *__restrict__ v, const StartDesc *__
         if (ASYNC && tid == 0) {
             if (s != extra_s) {
                 if (extra_relax) atomicAdd(starts[extra_s].work, extra_relax);
+                if (extra_units) atomicAdd(starts[extra_s].work + 2, extra_units);
                 extra_relax = 0;
+                extra_units = 0;
                 extra_s = s;
             }
             // (iter: the passes that followed the first one)
@@ -1856,19 +2057,37 @@ sweep_units_kernel(DevLayout L, const float *__restrict__ v, const StartDesc *__
 #pragma unroll
             for (int j = 0; j < NP; j++) nent += pc.n[plan.ra + j][0] + (two ? pc.n[plan.ra + j][1] : 0);
             extra_relax += (unsigned long long)inunit_passes * (unsigned long long)(wb * wc) * (unsigned long long)nent;
+            if (as.handoff) {
+                // (with hand-off the planner does not see every entry: the workers count the first pass too)
+                int nent1 = 0;
+                for (unsigned rest = my_planes & plane_mask; rest; rest &= rest - 1) {
+                    const int p = __builtin_ctz(rest);
+                    nent1 += pc.n[p][0] + (two ? pc.n[p][1] : 0);
+                }
+                extra_relax += (unsigned long long)(wb * wc) * (unsigned long long)nent1;
+                extra_units += 1ull;
+            }
         }
 #ifdef TTSWEEP_ASYNC_STATS
         if (ASYNC && improved && lane == 0) atomicOr(&head[12], 1);      // (tuning aid: did this unit improve anything?)
 #endif
+        const HandOff ho = make_handoff(s, q, defer_margin);
+        const bool ho_on = ASYNC && ho.on != 0;
         if (ASYNC) {
             // every wave's (write-through) stores have arrived, everybody knows it; then the bits
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            // (hand-off: the waves that finished cells of one own plane would tell the same units - the first of them
+            // would take an idle one and publish it, the bits of the others would make it due once more: ONE wave per
+            // own plane tells, with what all of them improved)
+            if (ho_on && improved && lane == 0) atomicOr(&head[4 + fin_plane], improved);
             __syncthreads();
         }
-        if (improved) {         // (wave-uniform) the units that stage this plane have to look again
+        int told_improved = improved;
+        if (ho_on) told_improved = wave == fin_plane * (NS / NP) ? __builtin_amdgcn_readfirstlane(head[4 + fin_plane]) : 0;
+        if (told_improved) {    // (wave-uniform) the units that stage this plane have to look again
             const DeferRule rule{sdp->sa, sdp->sb, sdp->sc, defer_margin};
-            push_improved<NP>(L, plan.ra, btiles, cstrips, reinterpret_cast<unsigned *>(tile_flags + 2 * nflag),
-                              a, bt, cs, improved, lane, rule, reinterpret_cast<unsigned *>(tile_flags));
+            push_improved<NP, ASYNC>(L, plan.ra, btiles, cstrips, reinterpret_cast<unsigned *>(tile_flags + 2 * nflag),
+                                     a, bt, cs, told_improved, lane, rule, reinterpret_cast<unsigned *>(tile_flags), ho);
             // (the start's word: once per wave, start and pass - its few words are a hot spot)
             if (lane == 0 && s != flagged) atomicOr(&changed[s], CHANGED_IMPROVED);
             flagged = s;
@@ -1879,7 +2098,17 @@ sweep_units_kernel(DevLayout L, const float *__restrict__ v, const StartDesc *__
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
             if (tid == 0) {
-                atomicAnd(reinterpret_cast<unsigned *>(tile_flags + 2 * nflag) + my_unit, ~ASYNC_BUSY);
+                unsigned *const myw = reinterpret_cast<unsigned *>(tile_flags + 2 * nflag) + my_unit;
+                if (ho.on & ASYNC_HANDOFF_SELF) {
+                    // bits that arrived while the unit was being relaxed: it goes back into the ring at once
+                    const unsigned left = atomicAnd(myw, ~ASYNC_BUSY) & ~ASYNC_BUSY;
+                    if (left) {
+                        const unsigned planes = handoff_take(myw, left);
+                        if (planes) handoff_publish(ho, (unsigned)my_unit, planes);
+                    }
+                } else {
+                    atomicAnd(myw, ~ASYNC_BUSY);
+                }
                 atomicAdd(reinterpret_cast<unsigned *>(as.ctl + (size_t)q * ASYNC_CTL_STRIDE + 16), 1u);
 #ifdef TTSWEEP_ASYNC_STATS
                 // units / staged planes relaxed, and those of them that improved no cell (status[4 .. 7])
@@ -1902,18 +2131,21 @@ sweep_units_kernel(DevLayout L, const float *__restrict__ v, const StartDesc *__
             prof_acc[4] += (unsigned long long)p_comp;
             prof_acc[5] += (unsigned long long)(t_end - t_loop);      // (push, completion)
             prof_acc[6] += 1ull;
+            prof_vm += (unsigned long long)p_vm; prof_groups += (unsigned long long)p_groups;
         }
 #endif
     }
 #ifdef TTSWEEP_PROFILE
     if (tid == 0) {
         for (int i = 0; i < 7; i++) if (prof_acc[6]) atomicAdd(&g_prof[i], prof_acc[i]);
+        atomicAdd(&g_prof[8], prof_vm); atomicAdd(&g_prof[9], prof_groups);
         atomicAdd(&g_prof[7], (unsigned long long)(clock64() - t_k0));
     }
 #endif
 
     if (ASYNC) {                // (the host reads the words after the one launch)
         if (tid == 0 && extra_relax) atomicAdd(starts[extra_s].work, extra_relax);
+        if (tid == 0 && extra_units) atomicAdd(starts[extra_s].work + 2, extra_units);
         return;
     }
     // ---- the last workgroup to leave closes the pass: it hands the "changed" words to the
@@ -1939,12 +2171,12 @@ sweep_units_kernel(DevLayout L, const float *__restrict__ v, const StartDesc *__
     }
 }
 
-size_t units_lds_bytes(const StripPlan &plan, int nb)
+size_t units_lds_bytes(int waves)
 {
-    (void)plan; (void)nb;
-    size_t floats = (size_t)2 * SLAB_BYTES / 4;                             // two slabs of v and T rows
-    floats = std::max(floats, (size_t)STRIP_NS * STRIP_PLANES * STRIP_K * STRIP_TB);    // combine buffer
-    return (floats + STRIP_LDS_HEAD) * sizeof(float);
+    const int nslab = 2 * (waves == STRIP_NS_LAT ? STRIP_G_LAT : STRIP_G);
+    size_t floats = (size_t)nslab * SLAB_BYTES / 4;                         // the slabs of v and T rows
+    floats = std::max(floats, (size_t)waves * STRIP_PLANES * STRIP_K * STRIP_TB);       // combine buffer
+    return (floats + strip_lds_head(waves)) * sizeof(float);
 }
 
 hipError_t launch_plan_pass(const DevLayout &L, const StartDesc *starts, const int2 *work,
@@ -1978,8 +2210,9 @@ hipError_t launch_sweep_units(const DevLayout &L, const float *v, const StartDes
         return hipErrorInvalidValue;                    // (the last workgroup closes the pass)
     if (plan.np < 1 || plan.np > STRIP_PLANES) return hipErrorInvalidValue;
     const int btiles = strip_btiles(L);
-    auto kern = plan.np == 1 ? sweep_units_kernel<STRIP_K, 1, false> : sweep_units_kernel<STRIP_K, 2, false>;
-    const size_t lds = units_lds_bytes(plan, L.n[1]);
+    auto kern = plan.np == 1 ? sweep_units_kernel<STRIP_K, 1, false, STRIP_NS, STRIP_G>
+                             : sweep_units_kernel<STRIP_K, 2, false, STRIP_NS, STRIP_G>;
+    const size_t lds = units_lds_bytes(STRIP_NS);
     if (lds > 48 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -1992,15 +2225,18 @@ hipError_t launch_sweep_units(const DevLayout &L, const float *v, const StartDes
 }
 
 hipError_t launch_solve_units(const DevLayout &L, const float *v, const StartDesc *starts, int nblocks,
-                              int *changed, const StripItem *items, const StripPlan &plan,
+                              int *changed, const StripItem *items, const StripPlan &plan, int waves,
                               const UnitPassTail &tail, const AsyncSolve &as, int *flags0, long long flags_stride,
                               hipStream_t st)
 {
     if (as.nrings < 1 || as.nrings > ASYNC_MAX_RINGS || nblocks <= as.nrings) return hipErrorInvalidValue;
     if (plan.np < 1 || plan.np > STRIP_PLANES) return hipErrorInvalidValue;
     const int btiles = strip_btiles(L);
-    auto kern = plan.np == 1 ? sweep_units_kernel<STRIP_K, 1, true> : sweep_units_kernel<STRIP_K, 2, true>;
-    const size_t lds = units_lds_bytes(plan, L.n[1]);
+    if (waves != STRIP_NS && !(waves == STRIP_NS_LAT && plan.np == 1)) return hipErrorInvalidValue;
+    auto kern = waves == STRIP_NS_LAT ? sweep_units_kernel<STRIP_K, 1, true, STRIP_NS_LAT, STRIP_G_LAT>
+              : plan.np == 1 ? sweep_units_kernel<STRIP_K, 1, true, STRIP_NS, STRIP_G>
+                             : sweep_units_kernel<STRIP_K, 2, true, STRIP_NS, STRIP_G>;
+    const size_t lds = units_lds_bytes(waves);
     if (lds > 48 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -2009,7 +2245,7 @@ hipError_t launch_solve_units(const DevLayout &L, const float *v, const StartDes
     PlaneCounts pc;
     for (int p = 0; p < STRIP_STAGED; p++)
         for (int j = 0; j < STRIP_PLANES; j++) pc.n[p][j] = p < plan.nstaged ? plan.nent[p][j] : 0;
-    hipLaunchKernelGGL(kern, dim3((unsigned)nblocks), dim3(STRIP_TB, STRIP_NS), lds, st, L, v, starts,
+    hipLaunchKernelGGL(kern, dim3((unsigned)nblocks), dim3(STRIP_TB, waves), lds, st, L, v, starts,
                        (const int4 *)nullptr, 0, as.nrings, (int *)nullptr, changed, items, plan, btiles,
                        strip_cstrips(L), tail, as, pc, flags0, flags_stride);
     return hipGetLastError();

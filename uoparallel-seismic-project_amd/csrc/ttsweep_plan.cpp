@@ -118,6 +118,8 @@ static void make_layout_strip(ttsweep_ctx *ctx)
         plan.ra = r[0];
         plan.rb = L.lo[1];
     }
+    ctx->plan_lat.ra = r[0];
+    ctx->plan_lat.rb = L.lo[1];
 }
 
 // Padded layout for the TILE kernel: identity axis order (z stays the stride-1 axis),
@@ -196,20 +198,20 @@ void make_layout(ttsweep_ctx *ctx)
     else make_layout_cell(ctx);
 }
 
-static int upload_strip_plan_np(ttsweep_ctx *ctx, int np);
+static int upload_strip_plan_np(ttsweep_ctx *ctx, int np, int ns, StripPlan &plan, StripItem *&d_items);
 
 int upload_strip_plan(ttsweep_ctx *ctx)
 {
     for (int np = 1; np <= STRIP_PLANES; np++)
-        if (upload_strip_plan_np(ctx, np)) return -1;
-    return 0;
+        if (upload_strip_plan_np(ctx, np, STRIP_NS, ctx->plans[np - 1], ctx->d_strip_items[np - 1])) return -1;
+    return upload_strip_plan_np(ctx, 1, STRIP_NS_LAT, ctx->plan_lat, ctx->d_strip_items_lat);
 }
 
-static int upload_strip_plan_np(ttsweep_ctx *ctx, int np)
+static int upload_strip_plan_np(ttsweep_ctx *ctx, int np, int ns, StripPlan &plan, StripItem *&d_items)
 {
     const DevLayout &L = ctx->L;
-    StripPlan &plan = ctx->plans[np - 1];
     plan.np = np;
+    plan.ns = ns;
     // (da, db) columns of the pull star: all offsets that differ only in dc
     struct Col { int db; unsigned mask; float h[16]; };
     std::vector<std::vector<Col>> per_da(2 * plan.ra + 1);
@@ -264,25 +266,24 @@ static int upload_strip_plan_np(ttsweep_ctx *ctx, int np)
         // share contiguous in the flat list.
         auto cost = [](const StripItem &x) { return __builtin_popcount(x.mask[0]) + __builtin_popcount(x.mask[1]) + 3; };
         std::stable_sort(its.begin(), its.end(), [&](const StripItem &x, const StripItem &y) { return cost(x) > cost(y); });
-        std::vector<StripItem> share[STRIP_NS];
-        int load[STRIP_NS] = {};
+        std::vector<StripItem> share[STRIP_NS_MAX];
+        int load[STRIP_NS_MAX] = {};
         for (const auto &x : its) {
             int w = 0;
-            for (int k = 1; k < STRIP_NS; k++)
+            for (int k = 1; k < ns; k++)
                 if (load[k] < load[w]) w = k;
             share[w].push_back(x);
             load[w] += cost(x);
         }
         if (its.size() > 255) return set_error("star has too many columns per plane offset");
         plan.wsplit[p][0] = 0;
-        for (int w = 0; w < STRIP_NS; w++) {
-            flat.insert(flat.end(), share[w].begin(), share[w].end());
-            plan.wsplit[p][w + 1] = (unsigned char)(plan.wsplit[p][w] + share[w].size());
+        for (int w = 0; w < STRIP_NS_MAX; w++) {
+            if (w < ns) flat.insert(flat.end(), share[w].begin(), share[w].end());
+            plan.wsplit[p][w + 1] = (unsigned char)(plan.wsplit[p][w] + (w < ns ? share[w].size() : 0));
         }
     }
     plan.first[plan.nstaged] = (int)flat.size();
     if (flat.size() > 0xffff) return set_error("star has too many columns");
-    StripItem *&d_items = ctx->d_strip_items[np - 1];
     if (d_items) HIPCHK(hipFree(d_items));
     d_items = nullptr;
     if (!flat.empty()) {
@@ -446,6 +447,8 @@ int ensure_unit_grid(ttsweep_ctx *ctx)
             // measured optimum - a third one adds no throughput, lengthens every unit and lets
             // fewer units see their neighbours' updates of the same pass
         ctx->unitq_blocks = ((wgs + ctx->nlists - 1) / ctx->nlists) * ctx->nlists;
+        // (the latency instance: one eight-wave workgroup per CU)
+        ctx->unitq_blocks_lat = ((std::max(prop.multiProcessorCount, 1) + ctx->nlists - 1) / ctx->nlists) * ctx->nlists;
     }
     return 0;
 }

@@ -252,14 +252,15 @@ int sweepXYZ(int nx, int ny, int nz, int s, int starstart, int starstop)
             if (ndev > 64) ndev = 64;
             for (n = 0; n < ndev; n++) devices[n] = n;
             for (n = 0; n < numstart_g; n++) boxes[n] = ttboxes[n].flat;
-            rc = ttsweep_solve_multi(ndev, devices, nx, ny, nz, (const ttsweep_fs *)fs, starstart,
-                                     starstop, vbox.box.flat, numstart_g,
-                                     (const ttsweep_start *)start, boxes);
+            /* which boxes moved (:158-164 prints and sums this per start) */
+            for (n = 0; n < numstart_g; n++) result[n] = 0;
+            rc = ttsweep_solve_multi_changed(ndev, devices, nx, ny, nz, (const ttsweep_fs *)fs, starstart,
+                                             starstop, vbox.box.flat, numstart_g,
+                                             (const ttsweep_start *)start, boxes, result);
             if (rc < 0) {
                 printf("ttsweep: %s\n", ttsweep_last_error());
                 exit(1);
             }
-            for (n = 0; n < numstart_g; n++) result[n] = rc;
         }
         return result[s];
     }

@@ -89,21 +89,25 @@ def _same_host(dist) -> bool:
     return len(set(names)) == 1
 
 
-_cpu_group = None
+_cpu_group = None           # (default group it was made for, gloo group)
 
 
 def _host_group(dist):
-    """A process group that can move CPU tensors: the default one unless it is RCCL-only."""
+    """A process group that can move CPU tensors: the default one unless it is RCCL-only.  The gloo group made
+    for an RCCL-only default group is kept for as long as THAT default group lives: after destroy_process_group
+    and a new init (bench.py's fall-back to gloo, tests that make a one-rank nccl group) the cached handle would
+    belong to the destroyed world."""
     global _cpu_group
     if "gloo" in str(dist.get_backend()):
         return None                                 # (the default group does)
-    if _cpu_group is None:
-        _cpu_group = dist.new_group(backend="gloo")
-    return _cpu_group
+    world = dist.group.WORLD
+    if _cpu_group is None or _cpu_group[0] is not world:
+        _cpu_group = (world, dist.new_group(backend="gloo"))
+    return _cpu_group[1]
 
 
 def gather_boxes(local, nstart: int, dist=None, dst: int = 0, shards=None, path: str = "device",
-                 shm_dir: str = "/dev/shm", tag: str = "ttsweep", loopback: bool = False):
+                 shm_dir: str = "/dev/shm", tag: str = "ttsweep", loopback: bool = False, group=None):
     """Gather the per-rank stacks of boxes [n_local, nx, ny, nz] on rank `dst`, ordered by
     global start index ([nstart, nx, ny, nz]); other ranks return None.  Ranks may hold
     different numbers of starts (`shards`: the assignment in use, all_shards; round-robin when
@@ -118,6 +122,8 @@ def gather_boxes(local, nstart: int, dist=None, dst: int = 0, shards=None, path:
         boxes from its GPU straight into their slots (D2H over PCIe, all GPUs at once, no
         inter-process copy); ranks on different machines: the boxes travel as CPU tensors over
         a gloo group.  The returned tensor is a CPU tensor (shared mapping or plain).
+    group (path "device"): the process group the device transfers run in - an RCCL group next to a gloo default group
+        (bench.py: the default group carries the control traffic, RCCL only the gather); None: the default group.
     loopback (testing aid, path "device"): the root's own boxes travel like everybody else's - a send to
         itself and the matching receive in the same group -, also in a group of ONE rank: the collective
         path then runs on a single GPU (a one-rank `nccl` group is the only RCCL a one-GPU box offers)."""
@@ -140,15 +146,15 @@ def gather_boxes(local, nstart: int, dist=None, dst: int = 0, shards=None, path:
         if rank == dst:
             out = torch.empty((nstart,) + box_shape, dtype=local.dtype, device=local.device)
             if loopback:
-                ops += [dist.P2POp(dist.isend, local[n], dst) for n in range(len(mine))]
+                ops += [dist.P2POp(dist.isend, local[n], dst, group) for n in range(len(mine))]
             else:
                 for n, s in enumerate(mine):
                     out[s].copy_(local[n])
             for r in range(world):
                 if r != dst or loopback:
-                    ops += [dist.P2POp(dist.irecv, out[s], r) for s in shards[r]]
+                    ops += [dist.P2POp(dist.irecv, out[s], r, group) for s in shards[r]]
         else:
-            ops = [dist.P2POp(dist.isend, local[n], dst) for n in range(len(mine))]
+            ops = [dist.P2POp(dist.isend, local[n], dst, group) for n in range(len(mine))]
         if ops:
             for req in dist.batch_isend_irecv(ops):
                 req.wait()

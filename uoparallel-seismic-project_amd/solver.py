@@ -181,8 +181,9 @@ class TravelTimeSolver:
 
 
 def solve_multi(devices, v: np.ndarray, fs: np.ndarray, starts, tt_boxes, starstart: int = 0,
-                starstop: int | None = None) -> int:
-    """ttsweep_solve_multi: shard the starts round-robin over `devices` (host boxes)."""
+                starstop: int | None = None, changed: list | None = None) -> int:
+    """ttsweep_solve_multi[_changed]: shard the starts, balanced by cost, over `devices` (host boxes).
+    changed: a list that receives the per-start outcome (serial_new/...:158-164: changed[s])."""
     v = np.ascontiguousarray(v, dtype=np.float32)
     fs = np.ascontiguousarray(fs, dtype=FS_DTYPE)
     if starstop is None:
@@ -196,6 +197,13 @@ def solve_multi(devices, v: np.ndarray, fs: np.ndarray, starts, tt_boxes, starst
         ptrs[s] = box.ctypes.data
     dev = (C.c_int * len(devices))(*devices)
     nx, ny, nz = v.shape
+    if changed is not None:
+        out = (C.c_int * len(arr))()
+        rc = _check(_lib.lib().ttsweep_solve_multi_changed(len(devices), dev, nx, ny, nz, fs.ctypes.data,
+                                                           starstart, starstop, v.ctypes.data, len(arr), arr,
+                                                           ptrs, out), "ttsweep_solve_multi_changed")
+        changed[:] = list(out)
+        return rc
     return _check(_lib.lib().ttsweep_solve_multi(len(devices), dev, nx, ny, nz, fs.ctypes.data,
                                                  starstart, starstop, v.ctypes.data, len(arr), arr,
                                                  ptrs), "ttsweep_solve_multi")
