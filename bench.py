@@ -385,6 +385,7 @@ def main():
     ap.add_argument("--inunit", type=int, default=None, help="schedule knob: passes of a unit that improved against its own planes (one-launch STRIP solve)")
     ap.add_argument("--handoff", type=int, default=None, help="schedule knob: TTSWEEP_OPT_ASYNC_HANDOFF (workers publish successor units themselves)")
     ap.add_argument("--waves", type=int, default=None, choices=[-1, 4, 8], help="schedule knob: TTSWEEP_OPT_ASYNC_WAVES (waves that relax a unit)")
+    ap.add_argument("--special", type=int, default=None, help="schedule knob: TTSWEEP_OPT_ASYNC_SPECIAL")
     ap.add_argument("--cpu-b2", action="store_true",
                     help="BASELINE.md leg B2 in this run: start-1 relaxed to convergence in the reference's order on ONE host "
                          "core with the CPU restatement (about 190 s; not part of the driver's default run)")
@@ -511,6 +512,8 @@ def main():
         sol.set_option(P.OPT_ASYNC_HANDOFF, args.handoff)
     if args.waves is not None:
         sol.set_option(P.OPT_ASYNC_WAVES, args.waves)
+    if args.special is not None:
+        sol.set_option(P.OPT_ASYNC_SPECIAL, args.special)
     sol.set_velocity(v_dev)
     if args.prepass:
         sol.set_option(P.OPT_PREPASS_ENTRIES, args.prepass)

@@ -111,7 +111,7 @@ typedef struct ttsweep_ctx ttsweep_ctx;
 #define TTSWEEP_OPT_ASYNC_LOW     10  /* schedule only: a ring is refilled when it holds at most this many ... */
 #define TTSWEEP_OPT_ASYNC_HIGH    11  /* ... up to this many units (0: defaults from the grid of workgroups) */
 #define TTSWEEP_OPT_ASYNC_SPECIAL 12  /* schedule only: units of a start between two relaxations of its
-                                         dead-edge cells in a one-launch solve (default 128) */
+                                         dead-edge cells in a one-launch solve (default 32) */
 #define TTSWEEP_OPT_ASYNC_POLICY  13  /* schedule only: how a planner hands units out in a one-launch solve.
                                          0 = every refill of its ring starts at the unit nearest to the start
                                          (strict priority by distance); 1 (default) = the scan goes round and

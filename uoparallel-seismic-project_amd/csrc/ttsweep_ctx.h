@@ -83,8 +83,9 @@ struct ttsweep_ctx {
     StripPlan plan_lat{};
     int unitq_blocks_lat = 0;               // its resident grid (one workgroup per CU)
     int async_waves = -1;                   // TTSWEEP_OPT_ASYNC_WAVES: 4 / 8 waves per unit; -1: by the size of the solve
-    long long lat_max_units = 16000;        // (default rule) starts x one-plane units of a start below which the latency instance runs
-                                            // (241x241x51: up to 4 starts; measured 1 start 5.9 -> 5.0 ms, 3 starts 7.5 -> 7.2, 8 starts 11.8 -> 15)
+    long long lat_max_units = 12000;        // (default rule) starts x one-plane units of a start below which the latency instance runs
+                                            // (241x241x51: up to 3 starts; measured 1 / 2 / 3 starts 6.0 -> 5.0, 6.8 -> 6.4, 7.6 -> 7.2 ms; 4 starts 8.4 -> 8.7,
+                                            // 6 starts 10.3 -> 12.7: profiles/r05_small_shards_and_special.txt)
     int np = ttsweep::STRIP_PLANES;
     int pair_min_starts = -1;               // two-plane units from this many starts on; -1: by the supply of units
     long long pair_min_units = 80000;       //   (starts x one-plane units of a start; measured crossover)
@@ -115,7 +116,7 @@ struct ttsweep_ctx {
     // STRIP, one launch per solve (AsyncSolve, ttsweep_dev.h)
     int async_mode = -1;                    // TTSWEEP_OPT_ASYNC
     int async_low = 0, async_high = 0;      // 0: defaults (solve_async_strip)
-    int async_special_every = 128;
+    int async_special_every = 32;           // (128 until round 5: 24 starts 28.5 -> 28.1 ms with 32, 1 and 8 the same, 512 29.6: profiles/r05_small_shards_and_special.txt)
     int async_timeout_ms = 0;               // TTSWEEP_OPT_ASYNC_TIMEOUT_MILLI (0: from the size of the solve)
     int async_policy = 1;                   // TTSWEEP_OPT_ASYNC_POLICY
     float async_gate_speed = 0.5f;          // cells per round (policy 1; TTSWEEP_OPT_ASYNC_GATE_MILLI)

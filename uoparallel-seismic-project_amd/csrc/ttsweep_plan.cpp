@@ -523,6 +523,11 @@ void order_units(const ttsweep_ctx *ctx, const StartDesc &sd, std::vector<int> &
     const int btiles = strip_btiles(L), cstrips = strip_cstrips(L);
     const int np = ctx->np;
     const int nunits = strip_units(L, np);
+    // (round 5, for the volumes that leave the caches: within shells of 4 ... 32 cells around the start the units
+    // ordered by position - plane group, lane tile, strip - so that units handed out one after the other stage
+    // overlapping windows: 512x512x256 x 8 291 -> 339 ... 362 ms, 6.8 -> 8.0 ... 8.6 sweep equivalents of work at the
+    // same speed per relaxation - the order by distance is what keeps the work low, and the staging traffic is not what
+    // limits that grid: profiles/r05_unit_order_shells.txt; removed)
     std::vector<std::pair<long long, int>> key(nunits);
     for (int t = 0; t < nunits; t++) {
         const int cs = t % cstrips, bt = (t / cstrips) % btiles, A = t / (cstrips * btiles);
