@@ -604,7 +604,7 @@ def main():
                      "shard_cost_estimate": round(sum(P.multistart.start_cost(starts[i], (nx, ny, nz)) for i in mine), 1),
                      "solve_ms": phase["solve_s"] / k * 1e3, "solve_device_ms": phase["solve_device_ms"] / k,
                      "gather_ms": phase["gather_s"] / k * 1e3, "step_ms": dt_local / max(args.steps, 1) * 1e3,
-                     "full_sweep_equivalents": relaxed_local / cells / max(args.steps, 1),
+                     "full_sweep_equivalents_per_start": relaxed_local / cells / max(args.steps, 1) / max(len(mine), 1),
                      "fallbacks": phase["fallbacks"]}
         ranks_info = [None] * world
         dist.all_gather_object(ranks_info, mine_info)
