@@ -295,6 +295,44 @@ def test_full_size_digests(P, full):
             assert hashlib.sha256(tt.tobytes()).hexdigest() == want["sha256"], (sname, start)
 
 
+@pytest.mark.parametrize("nstart,options", [
+    (1, {}),                                                    # the latency instance by the default rule
+    (3, {}),                                                    # one GPU's shard of BASELINE config 3
+    (3, {"OPT_ASYNC_WAVES": 4}),
+    (3, {"OPT_ASYNC_WAVES": 8, "OPT_ASYNC_HANDOFF": 3}),
+    (3, {"OPT_ASYNC_WAVES": 4, "OPT_ASYNC_HANDOFF": 1, "OPT_ASYNC_SPECIAL": 1}),
+    (8, {"OPT_ASYNC_WAVES": 8, "OPT_ASYNC_HANDOFF": 1}),       # (eight rings, one start each: the case that found the
+                                                                #  dead-edge entry without a reserved position)
+    (24, {"OPT_ASYNC_HANDOFF": 3}),
+], ids=["1-default", "3-default", "3-waves4", "3-waves8-handoff3", "3-waves4-handoff1-special1", "8-waves8-handoff1", "24-handoff3"])
+def test_full_size_small_shards_and_handoff(P, full, nstart, options):
+    """BASELINE config 3's shards (3 of the 24 starts per GPU) and the other sizes the round-5 schedule treats
+    differently - the eight-wave latency instance, direct hand-off - on the full-size grid, device-resident and
+    initialised on the device: every box is the reference's, bit for bit (SHA-256 from the unmodified reference's runs,
+    tests/golden/big_digests.json), the launch never gives up, and a second solve of the converged boxes stores
+    nothing."""
+    import torch
+    digests = json.load(open(os.path.join(GOLDEN, "big_digests.json")))
+    starts = np.asarray(P.inputs.read_triples(P.inputs.starts_path("24")), dtype=np.int32)[:nstart]
+    fs = P.inputs.make_fs(P.inputs.read_triples(P.inputs.star_path("818")))
+    dev = torch.device("cuda:0")
+    tt = torch.empty((nstart,) + full.shape, dtype=torch.float32, device=dev)
+    with P.TravelTimeSolver(full.shape, fs) as sol:
+        for key, value in options.items():
+            sol.set_option(getattr(P, key), value)
+        sol.set_velocity(full)
+        assert sol.solve_device(starts, tt, init=True) == 1
+        st = sol.stats()
+        assert st["launches"] == 1 and st["fallbacks"] == 0 and st["kernel_variant"] == 2
+        host = tt.cpu().numpy()
+        assert sol.solve_device(starts, tt, init=False) == 0
+        assert sol.stats()["fallbacks"] == 0
+        assert torch.equal(tt.cpu(), torch.from_numpy(host))
+    for s, box in zip(starts, host):
+        want = digests["syn241_818_%d_%d_%d" % tuple(int(x) for x in s)]["sha256"]
+        assert hashlib.sha256(box.tobytes()).hexdigest() == want, tuple(s)
+
+
 def test_full_size_fixed_point_properties(P, oracle, full):
     """start-4 (the BASELINE config), 818-FS: no INFINITY left, start at 0, a second
     solve changes nothing, and the oracle's validator finds no relaxable edge
