@@ -301,11 +301,18 @@ __device__ __forceinline__ void col_work_add(const ColumnSolve &P, ColWork &w, i
 
 // Lanes 0 .. 4 poll one progress word each (pa; !valid: nothing to wait for) until its key reaches `need`.
 // false: the solve is over for this column (the start is at rest, the solve has failed or ended).
+// first_done: the start's "at rest" word is read with the first round of the poll (lane 7) - a column claimed for a
+// start that has come to rest leaves here, without a round trip of its own in front of the poll.
 __device__ __forceinline__ bool col_poll(const ColumnSolve &P, const unsigned long long *pa, bool valid, unsigned need,
-                                         unsigned long long &pv, int s, long long deadline)
+                                         unsigned long long &pv, int s, long long deadline, bool first_done = false)
 {
     for (unsigned spin = 0;; spin++) {
         pv = valid ? cld64(pa) : ~0ull;
+        if (first_done && spin == 0u) {
+            unsigned dn = 0u;
+            if ((threadIdx.x & 63) == 7) dn = cld32(reinterpret_cast<const unsigned *>(P.done + s));
+            if (__ballot(dn != 0u) != 0ull) return false;
+        }
         const bool ok = !valid || (unsigned)(pv >> 32) >= need;
         if (__ballot(!ok) == 0ull) return true;
         if ((spin & 3u) == 3u) {
@@ -437,6 +444,8 @@ column_solve_kernel(const ColumnSolve P)
     const int seqlen = P.seq_len[seq];
     const int *const seqtab = P.seqtab + P.seq_off[seq];
     const long long per = (long long)seqlen * P.nstart;         // entries of one sweep in this sequence
+    const bool small_claims = per > 0 && per < (1ll << 20);
+    const float inv_per = 1.0f / (float)per, inv_nstart = 1.0f / (float)P.nstart;
 
     ColWork work;
 #ifdef TTSWEEP_COL_PROFILE
@@ -452,13 +461,32 @@ column_solve_kernel(const ColumnSolve P)
         unsigned long long q = 0;
         if (lane == 0) q = atomicAdd(P.claim + seq * 16, 1ull);
         q = ((unsigned long long)(unsigned)cuni((int)(q >> 32)) << 32) | (unsigned)cuni((int)(unsigned)q);
-        const long long qs = (long long)(q / (unsigned long long)per);
-        const int rem = (int)(q - (unsigned long long)qs * (unsigned long long)per);
+        // q = (sweep, position, start): two divisions by numbers that are fixed for the launch - a 64-bit and a 32-bit
+        // integer division are a hundred and more instructions per claim; a reciprocal estimate is off by at most one
+        // (sweep < 4096, position x start < 2^20: the float's 24 bits leave 1e-3 of a unit), corrected exactly
+        long long qs;
+        int rem;
+        if (small_claims) {
+            qs = (long long)(unsigned)cuni((int)(unsigned)((float)q * inv_per));
+            long long r = (long long)q - qs * per;
+            if (r < 0) { qs--; r += per; } else if (r >= per) { qs++; r -= per; }
+            rem = (int)r;
+        } else {
+            qs = (long long)(q / (unsigned long long)per);
+            rem = (int)(q - (unsigned long long)qs * (unsigned long long)per);
+        }
         if (qs >= COL_MAX_SWEEPS - 2) { col_fail(P, COL_ERR_CAP); break; }
         const int e = 1 + (int)qs;                              // sweep, 1-based
-        const int pos = rem / P.nstart, s = rem - pos * P.nstart;
+        int pos, s;
+        if (small_claims) {
+            pos = cuni((int)((float)rem * inv_nstart));
+            s = rem - pos * P.nstart;
+            if (s < 0) { pos--; s += P.nstart; } else if (s >= P.nstart) { pos++; s -= P.nstart; }
+        } else {
+            pos = rem / P.nstart;
+            s = rem - pos * P.nstart;
+        }
         CPROF_ADD(8, 1);
-        if (cld32(reinterpret_cast<const unsigned *>(P.done + s)) != 0u) { CPROF_ADD(9, 1); CPROF_ADD(1, CPROF_NOW() - pt0); continue; }
         const int packed = seqtab[pos];
         const int ip = packed & 0xffff, jp = packed >> 16;
         // the eight orderings in Gray-code order: successive sweeps differ in ONE sign, so sweep e + 1 starts at a corner
@@ -492,23 +520,31 @@ column_solve_kernel(const ColumnSolve P)
         cc.hz = P.h[2];
         cc.sigact = (I * TILE_X + ci < L.n[0] && J * TILE_Y + cj < L.n[1]) ? sig : 0x3fffffff;
 
-        // ---- the progress words of this column (lane 0), its upwind (1, 2) and downwind (3, 4) neighbours
-        unsigned long long *const prog = P.prog + (size_t)s * ncol;
+        // ---- the progress words of this column (lane 0), its upwind (1, 2) and downwind (3, 4) neighbours.  The words
+        // are kept twice, by the parity of the sweep: sweep e writes buffer e & 1, and what the columns sealed sweep
+        // e - 1 with - their improved tiles - stays readable in the other buffer until sweep e + 1 (which none of the
+        // five can begin before this column has sealed e).  From those masks the column derives the tiles that are due
+        // in sweep e from earlier sweeps - round 4 kept them in a word of bits per column, set with three atomics (and a
+        // wait in front of the seal) by every column that improved, fetched with a returning atomic by every column.
+        unsigned long long *const prog = P.prog + ((size_t)(e & 1) * P.nstart + s) * ncol;              // this sweep's
+        const unsigned long long *const prog_prev = P.prog + ((size_t)((e - 1) & 1) * P.nstart + s) * ncol;
         const int col = I * P.NJ + J;
         int ncolumn = col;
         bool valid = lane == 0;
-        if (lane == 1) { valid = ip > 0; ncolumn = (I - sx) * P.NJ + J; }
-        if (lane == 2) { valid = jp > 0; ncolumn = I * P.NJ + (J - sy); }
+        if (lane == 1 || lane == 5) { valid = ip > 0; ncolumn = (I - sx) * P.NJ + J; }
+        if (lane == 2 || lane == 6) { valid = jp > 0; ncolumn = I * P.NJ + (J - sy); }
         if (lane == 3) { valid = ip < P.NI - 1; ncolumn = (I + sx) * P.NJ + J; }
         if (lane == 4) { valid = jp < P.NJ - 1; ncolumn = I * P.NJ + (J + sy); }
         if (!valid) ncolumn = col;
-        const unsigned long long *const pa = prog + ncolumn;
+        const unsigned long long *const pa = prog + ncolumn;      // (lanes 1, 2: the upwind columns' words of THIS sweep)
         unsigned long long pv = 0;
-        // nobody is still in sweep e - 1 around this column
+        // nobody is still in sweep e - 1 around this column (lanes 0 .. 4: the five words of sweep e - 1); the same round
+        // brings the upwind columns' words of this sweep (lanes 5, 6: nothing to wait for) and the start's word (lane 7)
         const long long pt1 = CPROF_NOW();
         (void)pt1;
         CPROF_ADD(1, pt1 - pt0);
-        if (!col_poll(P, pa, valid && lane < 5, col_key(e - 1, 0xff), pv, s, deadline)) continue;
+        if (!col_poll(P, lane < 5 ? prog_prev + ncolumn : pa, valid && lane < 7, lane < 5 ? col_key(e - 1, 0xff) : 0u, pv, s, deadline,
+                      /*first_done=*/true)) { CPROF_ADD(9, 1); continue; }
         long long pt2 = CPROF_NOW();
         (void)pt2;
         CPROF_ADD(2, pt2 - pt1);
@@ -522,15 +558,40 @@ column_solve_kernel(const ColumnSolve P)
         // quiet column, 44 % of the claims of a solve, stages nothing, and the invalidate with its wait is 1.7 us)
         bool need_acquire = true;
         const bool upvalid = valid && (lane == 1 || lane == 2);
+
+        // the tiles that are due from earlier sweeps: whoever came EARLIER in sweep e - 1's order than an improved tile
+        // and touches it has to look again - the column itself (the improved tiles and the tile below each in that
+        // order) and the two columns it was the upwind column of: their sealed words (absolute K -> this sweep's order)
+        unsigned mask0 = 0;
+        if (e == 1) {
+            if (lane == 0) mask0 = cld32(P.due + (size_t)s * ncol + col);       // (the first sweep: what column_init marked)
+            mask0 = (unsigned)cuni((int)mask0);
+        } else {
+            const int op = ((e - 2) ^ ((e - 2) >> 1)) & 7;                      // the ordering of sweep e - 1
+            const int sxp = (op & 1) ? -1 : 1, syp = (op & 2) ? -1 : 1, szp = (op & 4) ? -1 : 1;
+            const unsigned mlo = (unsigned)pv;
+            const bool lv = valid;
+            const unsigned own = (unsigned)__builtin_amdgcn_readlane((int)mlo, 0);
+            // (the column this one was upwind of along x in sweep e - 1 is its downwind neighbour of this sweep when x kept
+            // its sign - lane 3 -, its upwind neighbour when x flipped - lane 1; y: lanes 4 / 2)
+            const unsigned m1 = __builtin_amdgcn_readlane(lv ? (int)mlo : 0, 1), m2 = __builtin_amdgcn_readlane(lv ? (int)mlo : 0, 2);
+            const unsigned m3 = __builtin_amdgcn_readlane(lv ? (int)mlo : 0, 3), m4 = __builtin_amdgcn_readlane(lv ? (int)mlo : 0, 4);
+            unsigned m = own | (own >> 1) | (sxp == sx ? m3 : m1) | (syp == sy ? m4 : m2);
+            if (szp < 0) m = col_flip(m, P.NK);
+            mask0 = m & (P.NK >= 32 ? ~0u : ((1u << P.NK) - 1u));
+        }
+        if (sz < 0) mask0 = col_flip(mask0, P.NK);
+
+        // what the upwind columns have finished of THIS sweep (their words came with the poll: lanes 5, 6 -> 1, 2)
+        {
+            const unsigned lo5 = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)pv, 5), hi5 = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(pv >> 32), 5);
+            const unsigned lo6 = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)pv, 6), hi6 = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(pv >> 32), 6);
+            if (lane == 1) pv = ((unsigned long long)hi5 << 32) | lo5;
+            if (lane == 2) pv = ((unsigned long long)hi6 << 32) | lo6;
+        }
         int known_up = 0;
         unsigned upmask = 0;
         col_upwind(pv, upvalid, e, P.NK, known_up, upmask);
-
-        // the tiles that are due from earlier sweeps (absolute K -> sweep order)
-        unsigned mask0 = 0;
-        if (lane == 0) mask0 = atomicExch(P.due + (size_t)s * ncol + col, 0u);
-        mask0 = (unsigned)cuni((int)mask0);
-        if (sz < 0) mask0 = col_flip(mask0, P.NK);
         CTRACE(1u, mask0, known_up, upmask, (unsigned)col_clock());
 
         const float *const vcol = P.v + (long long)(I * TILE_X) * L.s0 + (long long)(J * TILE_Y) * L.s1 + L.lo[2];
@@ -745,26 +806,14 @@ column_solve_kernel(const ColumnSolve P)
         (void)ps0;
         if (prof_runs == 0) CPROF_ADD(10, 1);
 
-        // ---- seal: the column is done with sweep e
-        if (mymask != 0u) {
-            if (published < P.NK && lane == 0)      // (the downwind columns go on while the bits are being set)
-                __hip_atomic_store(prog + col, ((unsigned long long)col_key(e, P.NK) << 32) | mymask, __ATOMIC_RELAXED,
-                                   __HIP_MEMORY_SCOPE_AGENT);
-            // whoever comes EARLIER in this sweep's order and touches an improved tile has to look again: the
-            // tile itself (other orderings), the tile below it in sweep order, the two upwind columns
-            const unsigned own = mymask | (mymask >> 1);
-            const unsigned own_abs = sz > 0 ? own : col_flip(own, P.NK), my_abs = sz > 0 ? mymask : col_flip(mymask, P.NK);
-            unsigned *const due = P.due + (size_t)s * ncol;
-            if (lane == 0) atomicOr(due + col, own_abs);
-            if (upvalid) atomicOr(due + ncolumn, my_abs);
-            if (lane == 0) P.changed[s] = CHANGED_IMPROVED;
-        }
+        // ---- seal: the column is done with sweep e.  (What it improved is in the word it seals with: the columns around
+        // it read their due tiles from it when they begin sweep e + 1.)
+        if (mymask != 0u && lane == 0) P.changed[s] = CHANGED_IMPROVED;
         // one count per start and sweep of the columns that are done with it, and of those that improved a tile: the
         // sweep's last column waits until every column has been counted, and rules on the start (nobody else waits)
         unsigned long long *const tally = P.seal + (size_t)s * COL_MAX_SWEEPS + e;
         if (lane == 0) atomicAdd(tally, 1ull | ((unsigned long long)(mymask != 0u) << 32));
         CTRACE(3u, mymask, o, upmask, (unsigned)col_clock());
-        if (mymask != 0u) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // (the bits are set before anybody sees the seal)
         if (lane == 0)
             __hip_atomic_store(prog + col, ((unsigned long long)col_key(e, 0xff) << 32) | mymask, __ATOMIC_RELAXED,
                                __HIP_MEMORY_SCOPE_AGENT);
@@ -812,7 +861,8 @@ column_init_kernel(ColumnSolve P, const StartDesc *__restrict__ starts, int from
         else if (abs(I - si) <= 1 && abs(J - sj) <= 1)
             for (int K = max(sk - 1, 0); K <= min(sk + 1, P.NK - 1); K++) m |= 1u << K;
         P.due[t] = m;
-        P.prog[t] = (unsigned long long)col_key(0, 0xff) << 32;
+        P.prog[t] = (unsigned long long)col_key(0, 0xff) << 32;                             // (both buffers: "sweep 0" sealed,
+        P.prog[(size_t)P.nstart * ncol + t] = (unsigned long long)col_key(0, 0xff) << 32;   //  nothing improved)
     }
     if (t < (long long)P.nstart * COL_MAX_SWEEPS) P.seal[t] = 0ull;
     if (t < P.nstart) { P.done[t] = 0; P.changed[t] = 0; }

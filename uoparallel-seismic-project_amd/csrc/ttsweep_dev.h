@@ -330,8 +330,9 @@ struct ColumnSolve {
     int nseq;                       // claim sequences in use (<= COL_SEQS)
     int seq_off[COL_SEQS], seq_len[COL_SEQS];
     const int *seqtab;              // sequence x: positions I' | J' << 16 in sweep order, from seq_off[x] on
-    unsigned long long *prog;       // [nstart][NI * NJ] progress words
-    unsigned *due;                  // [nstart][NI * NJ] due bits
+    unsigned long long *prog;       // [2][nstart][NI * NJ] progress words, a buffer per sweep parity
+    unsigned *due;                  // [nstart][NI * NJ] the tiles due in the FIRST sweep (column_init); later sweeps read
+                                    // them from the sealed progress words of the sweep before
     unsigned long long *seal;       // [nstart][COL_MAX_SWEEPS]: columns sealed | columns that improved << 32
     int *done;                      // [nstart]: the sweep after which the start was at rest (0: running)
     unsigned long long *claim;      // [COL_SEQS][16]: next entry of each sequence (128 bytes apart)

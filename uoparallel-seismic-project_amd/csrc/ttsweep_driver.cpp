@@ -502,7 +502,7 @@ static int solve_column(ttsweep_ctx *ctx, int nstart, bool from_box, float *cons
         ctx->d_col_prog = nullptr; ctx->d_col_due = nullptr; ctx->d_col_seal = nullptr; ctx->d_col_done = nullptr;
         ctx->h_col_done = nullptr;
         ctx->col_cap_starts = 0;
-        HIPCHK(hipMalloc((void **)&ctx->d_col_prog, (size_t)nstart * ncol * sizeof(unsigned long long)));
+        HIPCHK(hipMalloc((void **)&ctx->d_col_prog, (size_t)2 * nstart * ncol * sizeof(unsigned long long)));    // (two buffers, by sweep parity)
         HIPCHK(hipMalloc((void **)&ctx->d_col_due, (size_t)nstart * ncol * sizeof(unsigned)));
         HIPCHK(hipMalloc((void **)&ctx->d_col_seal, (size_t)nstart * COL_MAX_SWEEPS * sizeof(unsigned long long)));
         HIPCHK(hipMalloc((void **)&ctx->d_col_done, (size_t)nstart * sizeof(int)));
