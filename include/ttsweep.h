@@ -150,7 +150,7 @@ typedef struct ttsweep_ctx ttsweep_ctx;
 #define TTSWEEP_OPT_ASYNC_INUNIT 21   /* schedule only, never the result (STRIP kernel, one launch per solve): how often
                                          a unit that improved is relaxed again, at once, against its OWN planes - the
                                          values it has just stored - before it is handed back (-1, the default: 2 for
-                                         solves of 2 and more starts, 0 for a single start; 0 .. 8) */
+                                         solves of 2 and more starts, 0 for a single start and for the eight-wave instance of small shards; 0 .. 8) */
 
 #define TTSWEEP_OPT_ASYNC_HANDOFF 22  /* schedule only, never the result (STRIP kernel, one launch per solve): direct
                                          hand-off - a worker that has improved a plane not only tells the units that

@@ -34,10 +34,18 @@ with P.TravelTimeSolver(v.shape, fs) as sol:
             sol.set_option(P.OPT_DEFER_MARGIN_MILLI, int(rng.integers(-500, 4000)))
             sol.set_option(P.OPT_ASYNC_INUNIT, int(rng.integers(-1, 5)))
             sol.set_option(P.OPT_PAIR_MIN_STARTS, int(rng.choice([0, 1 << 20])))
+            # round 5: direct hand-off, the eight-wave instance of small shards (one-plane units), a short wall-clock limit
+            # on the launch (a solve that gives up would show as a fallback, below)
+            sol.set_option(P.OPT_ASYNC_HANDOFF, int(rng.integers(-1, 4)))
+            sol.set_option(P.OPT_ASYNC_WAVES, int(rng.choice([-1, 4, 8])))
+            sol.set_option(P.OPT_ASYNC_TIMEOUT_MILLI, 2000)
         nst = int(rng.integers(1, len(starts) + 1)) if it else len(starts)
         rc = sol.solve_device(starts[:nst], tt[:nst], init=True)
         torch.cuda.synchronize()
         assert rc == 1
+        if sol.stats()["fallbacks"]:
+            print(f"solve {it}: the launch gave up ({nst} starts)", flush=True)
+            bad += 1
         if first is None:
             first = tt.clone()
             host = first.cpu().numpy()

@@ -196,7 +196,6 @@ void ttsweep_destroy(ttsweep_ctx *ctx)
     (void)hipFree(ctx->d_work);
     (void)hipFree(ctx->d_tile_wgwork);
     (void)hipFree(ctx->d_col_prog);
-    (void)hipFree(ctx->d_col_seal);
     (void)hipFree(ctx->d_col_claim);
     (void)hipFree(ctx->d_col_due);
     (void)hipFree(ctx->d_col_status);

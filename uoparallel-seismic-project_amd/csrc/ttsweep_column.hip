@@ -18,10 +18,10 @@
 //     column reads while it reads it: every sweep computes exactly what the sequential ordering sweep computes.
 //     Successive sweeps overlap (sweep e + 1 follows sweep e across the grid), no launch, no host round trip.
 //   * A tile is relaxed in sweep e when it is DUE: a neighbour that comes later in the sweep order (or the tile
-//     itself) improved in an earlier sweep (bits in ColumnSolve::due), or an upwind neighbour improved in THIS
+//     itself) improved in the sweep before (read from the words the columns sealed it with), or an upwind neighbour improved in THIS
 //     sweep (the upwind columns' progress words carry the bits; inside the column the pipeline just goes on).
-//     A sweep in which no tile of a start improved leaves no bit: the start is at rest (columns are counted per
-//     start and sweep when they seal; the sweep's last column reads the count).
+//     A sweep in which no tile of a start improved leaves no bit: the start is at rest (every column hands a flag
+//     "a tile improved, here or upwind" on to its downwind columns; the sweep's last column reads it).
 // Visibility between workgroups (MI355X_MICROARCH.md, "inter-workgroup visibility"): travel times are stored
 // write-through (sc1), the storing wave waits for its stores (vmcnt(0)) before it publishes progress (an sc1
 // store); a wave that has read progress (sc1 loads) invalidates its L1 (buffer_inv sc1) before it stages.
@@ -123,8 +123,12 @@ __device__ __forceinline__ void col_fail(const ColumnSolve &P, unsigned code)
 }
 __device__ __forceinline__ unsigned col_flip(unsigned m, int nk) { return __brev(m) >> (32 - nk); }
 
-// progress word: sweep << 40 | tiles finished (0xff: sealed) << 32 | improved tiles (sweep order)
-__device__ __forceinline__ unsigned col_key(int sweep, int cnt) { return ((unsigned)sweep << 8) | (unsigned)cnt; }
+// progress word: sweep << 41 | tiles finished (0xff: sealed) << 33 | "a tile improved in this sweep, in this column or in
+// a column upwind of it, however far" << 32 | improved tiles of this column (sweep order).  The flag is final in the words
+// of a column that has finished all its tiles (its upwind columns then have): the LAST column of a sweep - every column
+// is upwind of it - reads from it whether the sweep improved anything (round 4 counted sealed and improved columns with
+// an atomic per column on a word per start and sweep, and the last column waited for the count).
+__device__ __forceinline__ unsigned col_key(int sweep, int cnt) { return ((unsigned)sweep << 9) | ((unsigned)cnt << 1); }
 
 // (the kernel has no static LDS: the dynamic array starts at LDS address 0 and an image offset IS the address -
 // checked on the host side of the launch; saves the addition of a base that is zero)
@@ -325,18 +329,22 @@ __device__ __forceinline__ bool col_poll(const ColumnSolve &P, const unsigned lo
 }
 
 // what the progress words of the two upwind columns (lanes 1 and 2: pv) say about sweep e
-__device__ __forceinline__ void col_upwind(unsigned long long pv, bool valid, int e, int NK, int &known, unsigned &mask)
+// upflag: |= the upwind columns' "improved, here or upwind" flags, once they have finished all their tiles
+__device__ __forceinline__ void col_upwind(unsigned long long pv, bool valid, int e, int NK, int &known, unsigned &mask, unsigned &upflag)
 {
-    const int sw = (int)(pv >> 40), cn = (int)((pv >> 32) & 0xffu);
+    const int sw = (int)(pv >> 41), cn = (int)((pv >> 33) & 0xffu);
     int c = NK;
     unsigned m = 0;
+    int fl = 0;
     if (valid) {
         c = sw == e ? min(cn, NK) : (sw > e ? NK : 0);
         m = sw == e ? (unsigned)pv : 0u;
+        fl = sw == e && cn >= NK ? (int)((pv >> 32) & 1ull) : 0;
     }
     const int c1 = __builtin_amdgcn_readlane(c, 1), c2 = __builtin_amdgcn_readlane(c, 2);
     known = min(c1, c2);
     mask = (unsigned)__builtin_amdgcn_readlane((int)m, 1) | (unsigned)__builtin_amdgcn_readlane((int)m, 2);
+    upflag |= (unsigned)(__builtin_amdgcn_readlane(fl, 1) | __builtin_amdgcn_readlane(fl, 2));
 }
 
 // -DTTSWEEP_COL_PROFILE: where the wavefronts' time goes (cycles summed over all wavefronts; tuning aid, never a result)
@@ -590,8 +598,8 @@ column_solve_kernel(const ColumnSolve P)
             if (lane == 2) pv = ((unsigned long long)hi6 << 32) | lo6;
         }
         int known_up = 0;
-        unsigned upmask = 0;
-        col_upwind(pv, upvalid, e, P.NK, known_up, upmask);
+        unsigned upmask = 0, upflag = 0;
+        col_upwind(pv, upvalid, e, P.NK, known_up, upmask, upflag);
         CTRACE(1u, mask0, known_up, upmask, (unsigned)col_clock());
 
         const float *const vcol = P.v + (long long)(I * TILE_X) * L.s0 + (long long)(J * TILE_Y) * L.s1 + L.lo[2];
@@ -637,7 +645,7 @@ column_solve_kernel(const ColumnSolve P)
                 (void)pw0;
                 if (!col_poll(P, pa, upvalid, col_key(e, k + 1), pv, s, deadline)) { alive = false; break; }
                 need_acquire = true;
-                col_upwind(pv, upvalid, e, P.NK, known_up, upmask);
+                col_upwind(pv, upvalid, e, P.NK, known_up, upmask, upflag);
                 CPROF_ADD(3, CPROF_NOW() - pw0);
             }
             const unsigned avail = known_up >= 32 ? ~0u : ((1u << known_up) - 1u);
@@ -711,11 +719,11 @@ column_solve_kernel(const ColumnSolve P)
                     if (kt >= P.NK) closed = true;                                                                 \
                     else {                                                                                         \
                         if (known_up <= kt) {                                                                      \
-                            col_upwind(pvn, upvalid, e, P.NK, known_up, upmask);                                   \
+                            col_upwind(pvn, upvalid, e, P.NK, known_up, upmask, upflag);                                   \
                             if (known_up <= kt) {                                                                  \
                                 const long long pq0 = CPROF_NOW();                                                 \
                                 if (!col_poll(P, pa, upvalid, col_key(e, kt + 1), pv, s, deadline)) { alive = false; closed = true; } \
-                                else col_upwind(pv, upvalid, e, P.NK, known_up, upmask);                           \
+                                else col_upwind(pv, upvalid, e, P.NK, known_up, upmask, upflag);                           \
                                 prof_inwait += (unsigned long long)(CPROF_NOW() - pq0);                            \
                             }                                                                                      \
                             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");                                     \
@@ -785,7 +793,8 @@ column_solve_kernel(const ColumnSolve P)
             mymask |= tilebits << k0;
             const int kend = k0 + nt;
             if (late && kend < P.NK) pend |= 1u << kend;
-            if (lane == 0) __hip_atomic_store(prog + col, ((unsigned long long)col_key(e, kend) << 32) | mymask,
+            // (kend == NK: the upwind columns have finished too - the flag is final)
+            if (lane == 0) __hip_atomic_store(prog + col, ((unsigned long long)(col_key(e, kend) | (kend >= P.NK && (mymask != 0u || upflag != 0u) ? 1u : 0u)) << 32) | mymask,
                                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             published = kend;
             CTRACE(2u, k0 | (nt << 8) | (kend << 16), tilebits, mask0 | upmask | pend, (unsigned)col_clock());
@@ -809,29 +818,18 @@ column_solve_kernel(const ColumnSolve P)
         // ---- seal: the column is done with sweep e.  (What it improved is in the word it seals with: the columns around
         // it read their due tiles from it when they begin sweep e + 1.)
         if (mymask != 0u && lane == 0) P.changed[s] = CHANGED_IMPROVED;
-        // one count per start and sweep of the columns that are done with it, and of those that improved a tile: the
-        // sweep's last column waits until every column has been counted, and rules on the start (nobody else waits)
-        unsigned long long *const tally = P.seal + (size_t)s * COL_MAX_SWEEPS + e;
-        if (lane == 0) atomicAdd(tally, 1ull | ((unsigned long long)(mymask != 0u) << 32));
         CTRACE(3u, mymask, o, upmask, (unsigned)col_clock());
+        const unsigned anyimp = mymask != 0u || upflag != 0u ? 1u : 0u;     // (every upwind column has finished: final)
         if (lane == 0)
-            __hip_atomic_store(prog + col, ((unsigned long long)col_key(e, 0xff) << 32) | mymask, __ATOMIC_RELAXED,
+            __hip_atomic_store(prog + col, ((unsigned long long)(col_key(e, 0xff) | anyimp) << 32) | mymask, __ATOMIC_RELAXED,
                                __HIP_MEMORY_SCOPE_AGENT);
-        if (ip == P.NI - 1 && jp == P.NJ - 1) {
-            unsigned long long seen = 0;
-            for (unsigned spin = 0;; spin++) {
-                seen = cld64(tally);
-                if ((unsigned)seen == (unsigned)ncol) break;
-                if ((spin & 3u) == 3u && (cld32(P.status) != COL_RUNNING || col_clock() > deadline)) break;
-                __builtin_amdgcn_s_sleep(4);
-            }
-            if ((unsigned)seen == (unsigned)ncol && (seen >> 32) == 0ull && lane == 0) {
-                // no tile of the start improved in sweep e: the start is at rest.  (Sweep e + 1 may be under way behind
-                // sweep e and come to the same end before its last column hears of this one: ONE of them counts.)
-                CTRACE(4u, (unsigned)seen, (unsigned)(seen >> 32), 0, (unsigned)col_clock());
-                if (atomicCAS(P.done + s, 0, e) == 0 && atomicSub(P.status + 1, 1u) == 1u)
-                    atomicCAS(P.status, (unsigned)COL_RUNNING, (unsigned)COL_DONE);
-            }
+        if (ip == P.NI - 1 && jp == P.NJ - 1 && anyimp == 0u && lane == 0) {
+            // the sweep's last column - every column is upwind of it, and has finished its tiles -: no tile of the start
+            // improved in sweep e: the start is at rest.  (Sweep e + 1 may be under way behind sweep e and come to the
+            // same end before its last column hears of this one: ONE of them counts.)
+            CTRACE(4u, 0, 0, 0, (unsigned)col_clock());
+            if (atomicCAS(P.done + s, 0, e) == 0 && atomicSub(P.status + 1, 1u) == 1u)
+                atomicCAS(P.status, (unsigned)COL_RUNNING, (unsigned)COL_DONE);
         }
         CPROF_ADD(7, CPROF_NOW() - ps0);
     }
@@ -864,7 +862,6 @@ column_init_kernel(ColumnSolve P, const StartDesc *__restrict__ starts, int from
         P.prog[t] = (unsigned long long)col_key(0, 0xff) << 32;                             // (both buffers: "sweep 0" sealed,
         P.prog[(size_t)P.nstart * ncol + t] = (unsigned long long)col_key(0, 0xff) << 32;   //  nothing improved)
     }
-    if (t < (long long)P.nstart * COL_MAX_SWEEPS) P.seal[t] = 0ull;
     if (t < P.nstart) { P.done[t] = 0; P.changed[t] = 0; }
     if (t < COL_SEQS * 16) P.claim[t] = 0ull;
     if (t == 0) { P.status[0] = COL_RUNNING; P.status[1] = (unsigned)P.nstart; }

@@ -141,7 +141,7 @@ struct ttsweep_ctx {
     int *d_tile_dmin = nullptr, *h_tile_dmin = nullptr;    // first hyperplane with a due tile, per sweep parity (device / pinned)
     // TILE, plain 6-neighbour star, one launch per solve (ColumnSolve, ttsweep_dev.h)
     ttsweep::ColumnSolve col{};
-    unsigned long long *d_col_prog = nullptr, *d_col_seal = nullptr, *d_col_claim = nullptr;
+    unsigned long long *d_col_prog = nullptr, *d_col_claim = nullptr;
     unsigned *d_col_due = nullptr, *d_col_status = nullptr, *h_col_status = nullptr;   // (h_: pinned)
     int *d_col_done = nullptr, *h_col_done = nullptr, *d_col_seqtab = nullptr;
     float **d_col_tptr = nullptr, **h_col_tptr = nullptr;  // the starts' travel-time volumes (h_: pinned)

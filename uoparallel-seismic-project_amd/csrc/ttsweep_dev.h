@@ -306,8 +306,9 @@ struct TileSweep {
 // behind the first lane; the pipeline does not drain between consecutive due tiles), through a ring of
 // three 16-cell chunks per image row in LDS.  Columns are claimed in the order of the sweep (by tile level
 // I' + J', per XCD sequence) and wait for each other through one 64-bit progress word per column and
-// start: sweep (24 bits) | tiles finished, 0xff = sealed (8) | tiles improved in this sweep (32, in sweep
-// order).  Which tiles are due in a LATER sweep is kept in one word of bits per column (absolute K).
+// start: sweep (23 bits) | tiles finished, 0xff = sealed (8) | a tile improved in this sweep here or upwind (1) |
+// tiles improved in this sweep (32, in sweep order).  Which tiles are due in the NEXT sweep the columns read from
+// the words their neighbours sealed this one with.
 constexpr int COL_MAX_NK = 32;              // tiles of a column (bits of a mask word)
 constexpr int COL_MAX_SWEEPS = 4096;        // per-start, per-sweep seal counters
 constexpr int COL_SEQS = 8;                 // claim sequences (one per XCD)
@@ -333,7 +334,6 @@ struct ColumnSolve {
     unsigned long long *prog;       // [2][nstart][NI * NJ] progress words, a buffer per sweep parity
     unsigned *due;                  // [nstart][NI * NJ] the tiles due in the FIRST sweep (column_init); later sweeps read
                                     // them from the sealed progress words of the sweep before
-    unsigned long long *seal;       // [nstart][COL_MAX_SWEEPS]: columns sealed | columns that improved << 32
     int *done;                      // [nstart]: the sweep after which the start was at rest (0: running)
     unsigned long long *claim;      // [COL_SEQS][16]: next entry of each sequence (128 bytes apart)
     unsigned *status;               // [0]: COL_RUNNING / COL_DONE / error; [1]: starts still running

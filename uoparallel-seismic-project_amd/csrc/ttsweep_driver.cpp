@@ -276,7 +276,9 @@ static int solve_async_strip(ttsweep_ctx *ctx, int nstart, std::vector<int> &swe
     // a unit that improved is relaxed again against its own planes, at once (measured: 24 starts 34.5 -> 29.4 ms with
     // two such passes - the planner hands out a third less -, 3 starts 7.85 -> 7.77, one start 6.38 -> 6.52:
     // profiles/r04_inunit.txt)
-    as.inunit = ctx->async_inunit >= 0 ? ctx->async_inunit : (nstart >= 2 ? 2 : 0);
+    // (the latency instance: none - its units come round again faster than a pass over their own planes pays:
+    // 3 starts 7.24 -> 7.13 ms, 1 start 5.16 -> 5.02, profiles/r05_lat_8shares_g3.txt)
+    as.inunit = ctx->async_inunit >= 0 ? ctx->async_inunit : (lat ? 0 : (nstart >= 2 ? 2 : 0));
     // Direct hand-off (ttsweep_dev.h, ASYNC_HANDOFF_*): for solves that cannot fill the machine - what bounds them is
     // how fast good values travel from unit to unit, and every hop through the planner's scan costs a round of it.
     // Every unit of a ring can sit in it at once (taken by a worker, not yet claimed): the rings must hold that.
@@ -496,15 +498,13 @@ static int solve_column(ttsweep_ctx *ctx, int nstart, bool from_box, float *cons
     if (nstart > ctx->col_cap_starts) {
         if (ctx->d_col_prog) HIPCHK(hipFree(ctx->d_col_prog));
         if (ctx->d_col_due) HIPCHK(hipFree(ctx->d_col_due));
-        if (ctx->d_col_seal) HIPCHK(hipFree(ctx->d_col_seal));
         if (ctx->d_col_done) HIPCHK(hipFree(ctx->d_col_done));
         if (ctx->h_col_done) HIPCHK(hipHostFree(ctx->h_col_done));
-        ctx->d_col_prog = nullptr; ctx->d_col_due = nullptr; ctx->d_col_seal = nullptr; ctx->d_col_done = nullptr;
+        ctx->d_col_prog = nullptr; ctx->d_col_due = nullptr; ctx->d_col_done = nullptr;
         ctx->h_col_done = nullptr;
         ctx->col_cap_starts = 0;
         HIPCHK(hipMalloc((void **)&ctx->d_col_prog, (size_t)2 * nstart * ncol * sizeof(unsigned long long)));    // (two buffers, by sweep parity)
         HIPCHK(hipMalloc((void **)&ctx->d_col_due, (size_t)nstart * ncol * sizeof(unsigned)));
-        HIPCHK(hipMalloc((void **)&ctx->d_col_seal, (size_t)nstart * COL_MAX_SWEEPS * sizeof(unsigned long long)));
         HIPCHK(hipMalloc((void **)&ctx->d_col_done, (size_t)nstart * sizeof(int)));
         HIPCHK(hipHostMalloc((void **)&ctx->h_col_done, (size_t)nstart * sizeof(int)));
         ctx->col_cap_starts = nstart;
@@ -545,7 +545,6 @@ static int solve_column(ttsweep_ctx *ctx, int nstart, bool from_box, float *cons
     C.seqtab = ctx->d_col_seqtab;
     C.prog = ctx->d_col_prog;
     C.due = ctx->d_col_due;
-    C.seal = ctx->d_col_seal;
     C.done = ctx->d_col_done;
     C.claim = ctx->d_col_claim;
     C.status = ctx->d_col_status;
