@@ -79,6 +79,54 @@ def test_sharded_solve_gathers_in_start_order(tmp_path, oracle, pkg, world, nsta
         assert np.array_equal(got[s].view(np.uint32), want.view(np.uint32)), s
 
 
+def group_worker(rank, world, port, port2, nstart, outdir):
+    """The process-group set-up of bench.py (round 5): the DEFAULT group carries the control traffic, the device
+    transfers of the gather run in a group of their own (there: RCCL beside a gloo default group; here: a second gloo
+    group), and every rank learns of a failed probe over the default group before it depends on that group."""
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import ttsweep_pkg
+    P = ttsweep_pkg.load()
+    data = dist.new_group(backend="gloo")
+    # the agreement: one rank's probe "fails" - every rank hears of it
+    errs = [None] * world
+    dist.all_gather_object(errs, "probe failed on rank 1" if rank == 1 else None)
+    assert [e for e in errs if e] == ["probe failed on rank 1"]
+    shape = (4, 3, 5)
+    shards = P.multistart.all_shards(nstart, world)
+    mine = shards[rank]
+    local = torch.stack([torch.full(shape, float(s)) for s in mine]) if mine else torch.empty((0,) + shape)
+    out = P.multistart.gather_boxes(local, nstart, dist, dst=0, shards=shards, path="device", group=data)
+    if rank == 0:
+        np.save(os.path.join(outdir, "gathered.npy"), out.numpy())
+    else:
+        assert out is None
+    dist.barrier()
+    dist.destroy_process_group()
+    # a second world in the same process: a cached helper group of the first one must not be used again
+    os.environ["MASTER_PORT"] = str(port2)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    assert P.multistart._host_group(dist) is None
+    out = P.multistart.gather_boxes(local, nstart, dist, dst=0, shards=shards, path="host", tag=f"ttsweep_t{port}")
+    if rank == 0:
+        np.save(os.path.join(outdir, "gathered2.npy"), out.numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_gather_in_a_group_of_its_own_and_after_a_new_world(tmp_path, pkg):
+    world, nstart = 3, 7
+    port, port2 = free_port(), free_port()
+    mp.spawn(group_worker, args=(world, port, port2, nstart, str(tmp_path)), nprocs=world, join=True)
+    for name in ("gathered.npy", "gathered2.npy"):
+        got = np.load(tmp_path / name)
+        assert got.shape == (nstart, 4, 3, 5)
+        for s in range(nstart):
+            assert (got[s] == float(s)).all(), (name, s)
+
+
 def test_shard_assignment_is_a_partition(pkg):
     for nstart in (0, 1, 4, 24, 111):
         for world in (1, 2, 4, 8):
