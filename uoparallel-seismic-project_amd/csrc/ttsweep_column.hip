@@ -350,6 +350,7 @@ __device__ __forceinline__ void col_upwind(unsigned long long pv, bool valid, in
 // -DTTSWEEP_COL_PROFILE: where the wavefronts' time goes (cycles summed over all wavefronts; tuning aid, never a result)
 #ifdef TTSWEEP_COL_PROFILE
 __device__ unsigned long long g_col_prof[16];
+__device__ long long g_col_rest_time[64];       // (wall clock, 100 MHz) at which start s came to rest; [63]: the launch's first stamp
 #define CPROF_NOW() col_cycles()
 #define CPROF_ADD(i, x) prof[i] += (unsigned long long)(x)
 __device__ __forceinline__ long long col_cycles()
@@ -405,11 +406,20 @@ void column_prof_dump()
     const double tot = (double)std::max<unsigned long long>(h[0], 1);
     fprintf(stderr, "column prof: share of resident wavefront time: claim+setup %.3f  wait(previous sweep) %.3f  wait(upwind) %.3f  "
             "run prologue %.3f  run steps %.3f  in-run waits %.3f  run end+seal %.3f | columns %llu (start at rest %llu, quiet %llu)  "
-            "runs %llu  tiles %llu  blocks %llu  cycles per block %.0f  per tile (steps only) %.0f\n",
+            "runs %llu  tiles %llu  blocks %llu  cycles per block %.0f  per tile (steps only) %.0f | after a wavefront's last run %.3f, before its first %.3f\n",
             h[1] / tot, h[2] / tot, h[3] / tot, h[4] / tot, h[5] / tot, h[6] / tot, h[7] / tot, h[8], h[9], h[10], h[11], h[12], h[13],
-            (double)h[5] / (double)std::max<unsigned long long>(h[13], 1), (double)h[5] / (double)std::max<unsigned long long>(h[12], 1));
+            (double)h[5] / (double)std::max<unsigned long long>(h[13], 1), (double)h[5] / (double)std::max<unsigned long long>(h[12], 1),
+            h[14] / tot, h[15] / tot);
     unsigned long long z[16] = {};
     (void)hipMemcpyToSymbol(HIP_SYMBOL(g_col_prof), z, sizeof(z));
+    long long t[64] = {};
+    (void)hipMemcpyFromSymbol(t, HIP_SYMBOL(g_col_rest_time), sizeof(t));
+    fprintf(stderr, "column prof: starts at rest after (ms):");
+    for (int s2 = 0; s2 < 63; s2++)
+        if (t[s2]) fprintf(stderr, " %.1f", (double)(t[s2] - t[63]) / 1.0e5);
+    fprintf(stderr, "\n");
+    long long zz[64] = {};
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_col_rest_time), zz, sizeof(zz));
 }
 #endif
 
@@ -423,6 +433,9 @@ column_solve_kernel(const ColumnSolve P)
     const DevLayout &L = P.L;
     const long long clock0 = col_clock();
     const long long deadline = clock0 + P.timeout_ticks;
+#ifdef TTSWEEP_COL_PROFILE
+    if (blockIdx.x == 0 && threadIdx.x == 0) g_col_rest_time[63] = clock0;
+#endif
     if ((unsigned)(unsigned long long)lp != (unsigned)lbase) {      // (CLDS_F: image offsets are used as LDS addresses)
         col_fail(P, COL_ERR_LDS_BASE);
         return;
@@ -781,6 +794,10 @@ column_solve_kernel(const ColumnSolve P)
             const long long pr2 = CPROF_NOW();
             (void)pr2;
             CPROF_ADD(5, (unsigned long long)(pr2 - pr1) - prof_inwait);
+#ifdef TTSWEEP_COL_PROFILE
+            prof[14] = (unsigned long long)pr2;         // (the end of this wavefront's last run, so far)
+            if (prof[15] == 0ull) prof[15] = (unsigned long long)pr1;      // (the beginning of its first)
+#endif
             CPROF_ADD(6, prof_inwait);
             CPROF_ADD(11, 1);
             CPROF_ADD(12, nt);
@@ -828,16 +845,24 @@ column_solve_kernel(const ColumnSolve P)
             // improved in sweep e: the start is at rest.  (Sweep e + 1 may be under way behind sweep e and come to the
             // same end before its last column hears of this one: ONE of them counts.)
             CTRACE(4u, 0, 0, 0, (unsigned)col_clock());
-            if (atomicCAS(P.done + s, 0, e) == 0 && atomicSub(P.status + 1, 1u) == 1u)
-                atomicCAS(P.status, (unsigned)COL_RUNNING, (unsigned)COL_DONE);
+            if (atomicCAS(P.done + s, 0, e) == 0) {
+#ifdef TTSWEEP_COL_PROFILE
+                if (s < 63) g_col_rest_time[s] = col_clock();
+#endif
+                if (atomicSub(P.status + 1, 1u) == 1u) atomicCAS(P.status, (unsigned)COL_RUNNING, (unsigned)COL_DONE);
+            }
         }
         CPROF_ADD(7, CPROF_NOW() - ps0);
     }
     col_work_flush(P, work);
 #ifdef TTSWEEP_COL_PROFILE
     prof[0] = (unsigned long long)(CPROF_NOW() - prof_begin);
+    // (14: from the wavefront's last run to its exit - the tail of the launch as this wavefront saw it; 15: from its
+    // entry to its first run)
+    prof[14] = prof[14] ? (unsigned long long)CPROF_NOW() - prof[14] : prof[0];
+    prof[15] = prof[15] ? prof[15] - (unsigned long long)prof_begin : 0ull;
     if (lane == 0)
-        for (int i = 0; i < 14; i++) atomicAdd(&g_col_prof[i], prof[i]);
+        for (int i = 0; i < 16; i++) atomicAdd(&g_col_prof[i], prof[i]);
 #endif
 }
 
