@@ -167,6 +167,10 @@ typedef struct ttsweep_ctx ttsweep_ctx;
                                          long - for shards too small to fill the machine).  -1 (default): by the size
                                          of the solve */
 
+#define TTSWEEP_OPT_TILE_ORDER 24     /* schedule only, never the result (TILE kernel, one launch per solve): which
+                                         sequence of the eight orderings (+-x, +-y, +-z) successive sweeps follow -
+                                         0 .. 6, see column_order_sequence() in csrc/ttsweep_column.hip */
+
 #define TTSWEEP_KERNEL_AUTO       0
 #define TTSWEEP_KERNEL_CELL       1   /* one thread per cell, star from global memory */
 #define TTSWEEP_KERNEL_STRIP      2   /* LDS-staged plane slabs, register strips */

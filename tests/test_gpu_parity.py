@@ -1045,6 +1045,43 @@ def test_column_driver_with_fewer_claim_sequences(P, oracle, queues):
             assert_bit_equal(tt[s].cpu().numpy(), want[s], f"{queues} sequences, start {starts[s]}")
 
 
+@pytest.mark.parametrize("order", [0, 1, 2, 3, 5, 8, 18, 29, 32, 53, 71, 93, 104])
+def test_column_driver_sequences_of_orderings(P, oracle, order):
+    """TTSWEEP_OPT_TILE_ORDER: the sequence of the eight orderings each start's sweeps follow (which table, from which
+    corner, which axis in which role - column_order_sequence) changes how many sweeps and how much work a solve is,
+    never the fixed point: ragged grids, starts in corners, on faces and in the middle, fresh and damaged boxes."""
+    import torch
+    six = P.inputs.read_triples(P.inputs.star_path("six"))
+    fs = P.inputs.make_fs(six)
+    for shape, seed in (((70, 33, 96), 71), ((24, 41, 160), 72)):
+        rng = np.random.default_rng(seed)
+        v = rng.uniform(0.1, 0.5, size=shape).astype(np.float32)
+        starts = np.array([[0, 0, 0], [shape[0] - 1, shape[1] - 1, shape[2] - 1], [shape[0] // 2, 3, shape[2] - 2],
+                           [shape[0] // 3, shape[1] // 2, shape[2] // 2], [shape[0] - 2, 1, 40]], dtype=np.int32)
+        want = [oracle.converge(v, oracle.make_star(six), st, order=1)[0] for st in starts]
+        with P.TravelTimeSolver(shape, fs) as sol:
+            sol.set_option(P.OPT_KERNEL, 3)
+            sol.set_option(P.OPT_TILE_ORDER, order)
+            sol.set_velocity(v)
+            tt = torch.empty((len(starts),) + shape, dtype=torch.float32, device=torch.device("cuda:0"))
+            assert sol.solve_device(starts, tt, init=True) == 1
+            st = sol.stats()
+            assert st["kernel_variant"] == 3 and st["launches"] == 1 and st["fallbacks"] == 0
+            for s in range(len(starts)):
+                assert_bit_equal(tt[s].cpu().numpy(), want[s], f"order {order}, {shape}, start {starts[s]}")
+            assert sol.solve_device(starts, tt, init=False) == 0
+            tt[:, : shape[0] // 2, :, 10:50] *= 1.25
+            tt[:, 3:9, 2:30, :] = float("inf")
+            for s in range(len(starts)):
+                tt[s][tuple(starts[s])] = 0
+            assert sol.solve_device(starts, tt, init=False) == 1
+            for s in range(len(starts)):
+                assert_bit_equal(tt[s].cpu().numpy(), want[s], f"order {order}, {shape}, start {starts[s]} (after damage)")
+    with pytest.raises(Exception):
+        with P.TravelTimeSolver((8, 8, 32), fs) as sol:
+            sol.set_option(P.OPT_TILE_ORDER, 105)
+
+
 def test_column_rest_is_declared_once_per_start(P):
     """Three starts that come to rest in different sweeps, many times over: successive sweeps of the column driver
     overlap, and two of them can both end without an improvement before either hears of the other - the start

@@ -1,6 +1,7 @@
 """Experiment: the TILE kernel's two drivers on the plain 6-neighbour star - column pipelines in ONE launch
 (TTSWEEP_OPT_ASYNC = -1 / 1; mode 2: with TTSWEEP_OPT_TILE_IN_PLACE = 0) against one launch per tile hyperplane (0): same boxes bit for bit, time, work.
-python tools/exp/col_probe.py nx,ny,nz nstart [reps] [modes e.g. 1,0]"""
+python tools/exp/col_probe.py nx,ny,nz nstart [reps] [modes e.g. 1,0]
+ORDERS=0,2,5: the one-launch modes once per sequence of orderings (TTSWEEP_OPT_TILE_ORDER), digests compared across all"""
 import sys, os, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch, ttsweep_pkg
@@ -17,8 +18,10 @@ fs = P.inputs.make_fs(P.inputs.read_triples(P.inputs.star_path("six")))
 starts = P.inputs.scaled_starts(P.inputs.read_triples(P.inputs.starts_path("111")), *shape)[:nstart]
 cells = shape[0] * shape[1] * shape[2]
 digest = {}
-for mode in modes:
+orders = [int(x) for x in os.environ.get("ORDERS", "-1").split(",")]     # (-1: the library's default)
+for mode, order in [(m, o) for m in modes for o in (orders if m else orders[:1])]:
     with P.TravelTimeSolver(shape, fs) as sol:
+        if order >= 0: sol.set_option(P.OPT_TILE_ORDER, order)
         sol.set_option(P.OPT_ASYNC, 1 if mode == 2 else mode)     # (mode 2: columns, in the library's padded volumes)
         if mode == 2:
             sol.set_option(P.OPT_TILE_IN_PLACE, 0)
@@ -33,14 +36,14 @@ for mode in modes:
             wall = (time.perf_counter() - t0) * 1e3
             st = sol.stats()
             gb = 12.0 * st["cells_relaxed"] / 1e9
-            print(f"mode {mode} {shape} x {nstart}: rc {rc} wall {wall:.2f} ms solve {st['solve_ms']:.2f} ms kernel {st['sweep_kernel_ms']:.2f} ms "
+            print(f"mode {mode} order {order} {shape} x {nstart}: rc {rc} wall {wall:.2f} ms solve {st['solve_ms']:.2f} ms kernel {st['sweep_kernel_ms']:.2f} ms "
                   f"launches {st['launches']} sweeps max {st['sweeps_max']} total {st['sweeps_total']} grid-eq {st['cells_relaxed'] / cells / nstart:.2f} "
                   f"algorithmic {gb / (max(st['sweep_kernel_ms'], 1e-9) / 1e3):.0f} GB/s over kernel, {gb / (st['solve_ms'] / 1e3):.0f} GB/s over solve, "
                   f"fallbacks {st['fallbacks']}", flush=True)
         rc2 = sol.solve_device(starts, tt, init=False)
         print(f"mode {mode}: second solve rc {rc2} fallbacks {sol.stats()['fallbacks']}", flush=True)
-        digest[mode] = [int(tt[s].view(torch.int32).to(torch.int64).sum().item()) for s in range(nstart)]
+        digest[(mode, order)] = [int(tt[s].view(torch.int32).to(torch.int64).sum().item()) for s in range(nstart)]
         if nstart <= 2 and cells <= 600 * 600 * 300:
             print("validate", [sol.validate_device(starts[s], tt[s]) for s in range(nstart)], flush=True)
-if len(modes) > 1:
-    print("digests equal:", all(digest[m] == digest[modes[0]] for m in modes))
+if len(digest) > 1:
+    print("digests equal:", all(d == next(iter(digest.values())) for d in digest.values()))

@@ -87,6 +87,7 @@ OPT_QUEUES = 20
 OPT_ASYNC_INUNIT = 21
 OPT_ASYNC_HANDOFF = 22
 OPT_ASYNC_WAVES = 23
+OPT_TILE_ORDER = 24
 KERNEL_AUTO, KERNEL_CELL, KERNEL_STRIP, KERNEL_TILE = 0, 1, 2, 3
 
 

@@ -200,6 +200,8 @@ void ttsweep_destroy(ttsweep_ctx *ctx)
     (void)hipFree(ctx->d_col_due);
     (void)hipFree(ctx->d_col_status);
     (void)hipFree(ctx->d_col_done);
+    (void)hipFree(ctx->d_col_ordseq);
+    if (ctx->h_col_ordseq) (void)hipHostFree(ctx->h_col_ordseq);
     (void)hipFree(ctx->d_col_seqtab);
     (void)hipFree(ctx->d_col_tptr);
     if (ctx->h_col_tptr) (void)hipHostFree(ctx->h_col_tptr);
@@ -311,6 +313,11 @@ int ttsweep_set_option(ttsweep_ctx *ctx, int key, long long value)
         ctx->async_window = (float)((double)value / 1000.0);
         return 0;
     case TTSWEEP_OPT_TILE_IN_PLACE: ctx->col_in_place_off = value == 0; return 0;
+    case TTSWEEP_OPT_TILE_ORDER:
+        if (value < 0 || value >= ttsweep::COL_ORDER_CHOICES)
+            return set_error("sweep order must be 0 .. %d", (int)ttsweep::COL_ORDER_CHOICES - 1);
+        ctx->col_order = (int)value;
+        return 0;
     case TTSWEEP_OPT_ASYNC_INUNIT:
         if (value < -1 || value > 8) return set_error("in-unit passes must be -1 (default rule) or 0 .. 8");
         ctx->async_inunit = (int)value;

@@ -350,6 +350,7 @@ __device__ __forceinline__ void col_upwind(unsigned long long pv, bool valid, in
 // -DTTSWEEP_COL_PROFILE: where the wavefronts' time goes (cycles summed over all wavefronts; tuning aid, never a result)
 #ifdef TTSWEEP_COL_PROFILE
 __device__ unsigned long long g_col_prof[16];
+__device__ long long g_col_sweep_time[64];      // (wall clock) at which the last column of sweep e of start 0 sealed
 __device__ long long g_col_rest_time[64];       // (wall clock, 100 MHz) at which start s came to rest; [63]: the launch's first stamp
 #define CPROF_NOW() col_cycles()
 #define CPROF_ADD(i, x) prof[i] += (unsigned long long)(x)
@@ -420,6 +421,13 @@ void column_prof_dump()
     fprintf(stderr, "\n");
     long long zz[64] = {};
     (void)hipMemcpyToSymbol(HIP_SYMBOL(g_col_rest_time), zz, sizeof(zz));
+    long long w[64] = {};
+    (void)hipMemcpyFromSymbol(w, HIP_SYMBOL(g_col_sweep_time), sizeof(w));
+    fprintf(stderr, "column prof: the last column of sweep e of start 0 sealed after (ms):");
+    for (int e2 = 1; e2 < 64; e2++)
+        if (w[e2]) fprintf(stderr, " %d:%.1f", e2, (double)(w[e2] - t[63]) / 1.0e5);
+    fprintf(stderr, "\n");
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_col_sweep_time), zz, sizeof(zz));
 }
 #endif
 
@@ -514,7 +522,8 @@ column_solve_kernel(const ColumnSolve P)
         // sweep e passed half-way through (x or y flipped) or at its own first corner (z flipped) and follows it across
         // the grid; in binary order every second change of sweep flips x and y together - the next sweep then starts
         // where the previous one ENDS and the two cannot overlap at all
-        const int o = ((e - 1) ^ ((e - 1) >> 1)) & 7;
+        const unsigned long long oseq = P.ordseq[s];
+        const int o = (int)(oseq >> (4 * ((e - 1) & 15))) & 7;
         const int sx = (o & 1) ? -1 : 1, sy = (o & 2) ? -1 : 1, sz = (o & 4) ? -1 : 1;
         const int I = sx > 0 ? ip : P.NI - 1 - ip, J = sy > 0 ? jp : P.NJ - 1 - jp;
         // the lane's image addresses of the ring period (made anew for every column, new ordering or not: a table that
@@ -588,7 +597,7 @@ column_solve_kernel(const ColumnSolve P)
             if (lane == 0) mask0 = cld32(P.due + (size_t)s * ncol + col);       // (the first sweep: what column_init marked)
             mask0 = (unsigned)cuni((int)mask0);
         } else {
-            const int op = ((e - 2) ^ ((e - 2) >> 1)) & 7;                      // the ordering of sweep e - 1
+            const int op = (int)(oseq >> (4 * ((e - 2) & 15))) & 7;             // the ordering of sweep e - 1
             const int sxp = (op & 1) ? -1 : 1, syp = (op & 2) ? -1 : 1, szp = (op & 4) ? -1 : 1;
             const unsigned mlo = (unsigned)pv;
             const bool lv = valid;
@@ -840,6 +849,9 @@ column_solve_kernel(const ColumnSolve P)
         if (lane == 0)
             __hip_atomic_store(prog + col, ((unsigned long long)(col_key(e, 0xff) | anyimp) << 32) | mymask, __ATOMIC_RELAXED,
                                __HIP_MEMORY_SCOPE_AGENT);
+#ifdef TTSWEEP_COL_PROFILE
+        if (ip == P.NI - 1 && jp == P.NJ - 1 && s == 0 && e < 64 && lane == 0) g_col_sweep_time[e] = col_clock();
+#endif
         if (ip == P.NI - 1 && jp == P.NJ - 1 && anyimp == 0u && lane == 0) {
             // the sweep's last column - every column is upwind of it, and has finished its tiles -: no tile of the start
             // improved in sweep e: the start is at rest.  (Sweep e + 1 may be under way behind sweep e and come to the
@@ -919,6 +931,63 @@ hipError_t launch_column_init(const ColumnSolve &P, const StartDesc *starts, boo
                                             COL_SEQS * 16);
     hipLaunchKernelGGL(column_init_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, P, starts, from_box ? 1 : 0);
     return hipGetLastError();
+}
+
+// The orderings of a start's successive sweeps (bit 0: x backwards, bit 1: y, bit 2: z), sixteen nibbles, repeated.
+// Every sequence visits all eight; what differs is how much work the solve is and what the step from one sweep to the
+// next costs.  A sweep follows the one before across the grid as closely as its columns' neighbours have sealed that
+// one: when only z flips (or nothing) it starts at the same corner, two levels behind; when x or y flips it starts at a
+// corner the sweep before passes HALF-WAY through - it lags (NI + NJ) / 2 levels, and in the sparse sweeps of a solve,
+// which are nothing but latency from level to level, that lag is the sweep's whole cost; x and y together: a whole
+// traversal.  The order along z is the column's own business, so z is the axis to flip most often - and in a velocity
+// model that changes mostly with depth the rays turn in z: the z-fastest sequences also converge in less work
+// (profiles/r05_col_sweep_order.txt: six-FS 1024x1024x512 x 14, 4.37 -> 3.13 grid sweeps per start, 120.7 -> 92 ms).
+//   which % 7: the sequence as seen from the corner (0, 0, 0);
+//   which / 7 % 3: the corner each start's first sweep begins at - 0: (0, 0, 0) for every start, 1: the corner NEAREST
+//     to the start (its first sweeps run into the largest octants), 2: the farthest;
+//   which / 21: 0 - x, y, z as the table says; 1 - per start, the lateral axis along which the start lies nearer to
+//     the middle of the grid plays the table's x, 2 - the other one; 3 - the three axes by how near to the middle the
+//     start lies along them play x, y, z (the nearest: x), 4 - the other way round.
+void column_order_sequence(int which, const int (&n)[3], const int (&at)[3], unsigned long long *seq)
+{
+    static const unsigned char table[COL_ORDER_SEQUENCES][16] = {
+        // 0: the reflected Gray code of rounds 3 - 5, x fastest (x flips 8 times in 16 sweeps, y 4, z 2, 2 repeats)
+        {0, 1, 3, 2, 6, 7, 5, 4, 4, 5, 7, 6, 2, 3, 1, 0},
+        // 1: the cyclic Gray code, x fastest (x 4 of 8, y 2, z 2)
+        {0, 1, 3, 2, 6, 7, 5, 4, 0, 1, 3, 2, 6, 7, 5, 4},
+        // 2: the cyclic Gray code, z fastest, then x
+        {0, 4, 5, 1, 3, 7, 6, 2, 0, 4, 5, 1, 3, 7, 6, 2},
+        // 3: reflected, z fastest
+        {0, 4, 5, 1, 3, 7, 6, 2, 2, 6, 7, 3, 1, 5, 4, 0},
+        // 4: cyclic, z fastest, then y
+        {0, 4, 6, 2, 3, 7, 5, 1, 0, 4, 6, 2, 3, 7, 5, 1},
+        // 5: z flips with EVERY sweep, x or y with every second one (that costs what the x or y flip costs alone)
+        {0, 4, 1, 5, 3, 7, 2, 6, 0, 4, 1, 5, 3, 7, 2, 6},
+        // 6: as 5, pairs in the other order
+        {0, 4, 5, 1, 7, 3, 2, 6, 0, 4, 5, 1, 7, 3, 2, 6},
+    };
+    if (which < 0 || which >= COL_ORDER_CHOICES) which = 0;
+    const int base = which % COL_ORDER_SEQUENCES, first = which / COL_ORDER_SEQUENCES % 3, axes = which / (3 * COL_ORDER_SEQUENCES);
+    unsigned x = 0;
+    for (int d = 0; d < 3 && first; d++)
+        if ((2 * at[d] >= n[d]) == (first == 1)) x |= 1u << d;
+    // how far from the nearer face, as a share of the axis: the larger, the more evenly the start splits the axis
+    const double cx = (double)std::min(at[0], n[0] - 1 - at[0]) / n[0], cy = (double)std::min(at[1], n[1] - 1 - at[1]) / n[1];
+    const double cz = (double)std::min(at[2], n[2] - 1 - at[2]) / n[2];
+    int role[3] = {0, 1, 2};        // the axis that plays the table's x, y, z
+    if (axes == 1 ? cy > cx : axes == 2 ? cx > cy : false) std::swap(role[0], role[1]);
+    if (axes == 3 || axes == 4) {
+        const double c[3] = {cx, cy, cz};
+        std::stable_sort(role, role + 3, [&](int a, int b) { return axes == 3 ? c[a] > c[b] : c[a] < c[b]; });
+    }
+    unsigned long long q = 0;
+    for (int e = 0; e < 16; e++) {
+        unsigned o = 0;
+        for (int d = 0; d < 3; d++)
+            if (table[base][e] >> d & 1) o |= 1u << role[d];
+        q |= (unsigned long long)(o ^ x) << (4 * e);
+    }
+    *seq = q;
 }
 
 hipError_t launch_column_solve(const ColumnSolve &P, int nblocks, hipStream_t st)

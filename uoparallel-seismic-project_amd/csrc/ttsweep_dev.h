@@ -341,6 +341,8 @@ struct ColumnSolve {
     int *changed;                   // per start: CHANGED_IMPROVED when anything improved
     float h[6];                     // d / 2 of the entries x-, y-, z-, z+, y+, x+
     int max_sweeps;
+    const unsigned long long *ordseq;   // [nstart] the orderings of the start's sweeps 1, 2, ...: a nibble each (bit 0: x
+                                    // backwards, 1: y, 2: z), repeated with period 16 - column_order_sequence()
     long long timeout_ticks;        // wall-clock ticks (100 MHz) after which every wait gives up
 };
 

@@ -512,10 +512,15 @@ static int solve_column(ttsweep_ctx *ctx, int nstart, bool from_box, float *cons
     if (nstart > ctx->col_cap_tptr) {
         if (ctx->d_col_tptr) HIPCHK(hipFree(ctx->d_col_tptr));
         if (ctx->h_col_tptr) HIPCHK(hipHostFree(ctx->h_col_tptr));
+        if (ctx->d_col_ordseq) HIPCHK(hipFree(ctx->d_col_ordseq));
+        if (ctx->h_col_ordseq) HIPCHK(hipHostFree(ctx->h_col_ordseq));
         ctx->d_col_tptr = nullptr; ctx->h_col_tptr = nullptr;
+        ctx->d_col_ordseq = nullptr; ctx->h_col_ordseq = nullptr;
         ctx->col_cap_tptr = 0;
         HIPCHK(hipMalloc((void **)&ctx->d_col_tptr, (size_t)nstart * sizeof(float *)));
         HIPCHK(hipHostMalloc((void **)&ctx->h_col_tptr, (size_t)nstart * sizeof(float *)));
+        HIPCHK(hipMalloc((void **)&ctx->d_col_ordseq, (size_t)nstart * sizeof(unsigned long long)));
+        HIPCHK(hipHostMalloc((void **)&ctx->h_col_ordseq, (size_t)nstart * sizeof(unsigned long long)));
         ctx->col_cap_tptr = nstart;
     }
     for (int s = 0; s < nstart; s++) ctx->h_col_tptr[s] = in_place ? tt_dev[s] : ctx->d_T + (size_t)s * L.cells;
@@ -553,6 +558,16 @@ static int solve_column(ttsweep_ctx *ctx, int nstart, bool from_box, float *cons
     static const int order[6] = {0, 1, 2, 3, 4, 5};     // (tile_star_is_six: x-, y-, z-, z+, y+, x+)
     for (int e = 0; e < 6; e++) C.h[e] = ctx->tile_ent[order[e]].h;
     C.max_sweeps = (int)std::min<long long>(ctx->max_sweeps, COL_MAX_SWEEPS - 2);
+    for (int s = 0; s < nstart; s++) {
+        const StartDesc &sd = ctx->h_starts[s];
+        const int at[3] = {sd.sa, sd.sb, sd.sc}, nn[3] = {L.n[0], L.n[1], L.n[2]};
+        column_order_sequence(ctx->col_order, nn, at, &ctx->h_col_ordseq[s]);
+#ifdef TTSWEEP_DEBUG_ENV
+        if (const char *q = getenv("TTSWEEP_COL_ORDSEQ")) ctx->h_col_ordseq[s] = strtoull(q, nullptr, 16);   // (sweep 1: the lowest nibble)
+#endif
+    }
+    HIPCHK(hipMemcpyAsync(ctx->d_col_ordseq, ctx->h_col_ordseq, (size_t)nstart * sizeof(unsigned long long), hipMemcpyHostToDevice, ctx->stream));
+    C.ordseq = ctx->d_col_ordseq;
     // every wait inside the launch gives up after this much wall clock (100 MHz ticks): ten seconds plus twenty
     // times what forty sweep equivalents should take at a quarter of the memory rate
     const double expect_s = (double)L.n[0] * L.n[1] * L.n[2] * (double)nstart * 12.0 * 40.0 / 2.0e12;
