@@ -31,6 +31,7 @@
 
 #include <algorithm>
 #include <cstdio>
+#include <cstring>
 #include <vector>
 
 namespace ttsweep {
@@ -350,6 +351,8 @@ __device__ __forceinline__ void col_upwind(unsigned long long pv, bool valid, in
 // -DTTSWEEP_COL_PROFILE: where the wavefronts' time goes (cycles summed over all wavefronts; tuning aid, never a result)
 #ifdef TTSWEEP_COL_PROFILE
 __device__ unsigned long long g_col_prof[16];
+__device__ unsigned long long g_col_sweep_work[64][4];  // per sweep: tiles relaxed, runs, cycles in runs, columns with a run (all starts)
+__device__ long long g_col_level_time[3][512];      // the last seal of every level of sweeps 14 .. 16 of start 6 (wall clock)
 __device__ long long g_col_sweep_time[64];      // (wall clock) at which the last column of sweep e of start 0 sealed
 __device__ long long g_col_rest_time[64];       // (wall clock, 100 MHz) at which start s came to rest; [63]: the launch's first stamp
 #define CPROF_NOW() col_cycles()
@@ -428,6 +431,25 @@ void column_prof_dump()
         if (w[e2]) fprintf(stderr, " %d:%.1f", e2, (double)(w[e2] - t[63]) / 1.0e5);
     fprintf(stderr, "\n");
     (void)hipMemcpyToSymbol(HIP_SYMBOL(g_col_sweep_time), zz, sizeof(zz));
+    // what the sweeps were: work, and how fast the late ones cross the grid
+    unsigned long long sw[64][4] = {};
+    (void)hipMemcpyFromSymbol(sw, HIP_SYMBOL(g_col_sweep_work), sizeof(sw));
+    fprintf(stderr, "column prof: per sweep (all starts) tiles / runs / columns with a run / microseconds per run (2.4 GHz):");
+    for (int e2 = 1; e2 < 64; e2++)
+        if (sw[e2][1]) fprintf(stderr, " %d: %llu/%llu/%llu/%.1f", e2, sw[e2][0], sw[e2][1], sw[e2][3], (double)sw[e2][2] / (double)sw[e2][1] / 2400.0);
+    fprintf(stderr, "\n");
+    static long long lt[3][512];
+    (void)hipMemcpyFromSymbol(lt, HIP_SYMBOL(g_col_level_time), sizeof(lt));
+    for (int q = 0; q < 3; q++) {
+        fprintf(stderr, "column prof: start 6 sweep %d, every 16th level's last seal (ms):", 14 + q);
+        for (int l = 0; l < 512; l += 16)
+            if (lt[q][l]) fprintf(stderr, " %d:%.2f", l, (double)(lt[q][l] - t[63]) / 1.0e5);
+        fprintf(stderr, "\n");
+    }
+    memset(lt, 0, sizeof(lt));
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_col_level_time), lt, sizeof(lt));
+    unsigned long long zs[64][4] = {};
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_col_sweep_work), zs, sizeof(zs));
 }
 #endif
 
@@ -810,6 +832,14 @@ column_solve_kernel(const ColumnSolve P)
             CPROF_ADD(6, prof_inwait);
             CPROF_ADD(11, 1);
             CPROF_ADD(12, nt);
+#ifdef TTSWEEP_COL_PROFILE
+            if (lane == 0 && e < 64) {
+                atomicAdd(&g_col_sweep_work[e][0], (unsigned long long)nt);
+                atomicAdd(&g_col_sweep_work[e][1], 1ull);
+                atomicAdd(&g_col_sweep_work[e][2], (unsigned long long)(pr2 - pr0));
+                if (prof_runs == 0) atomicAdd(&g_col_sweep_work[e][3], 1ull);
+            }
+#endif
             CPROF_ADD(13, j);
             prof_runs++;
             tilebits &= nt >= 32 ? ~0u : ((1u << nt) - 1u);
@@ -851,6 +881,7 @@ column_solve_kernel(const ColumnSolve P)
                                __HIP_MEMORY_SCOPE_AGENT);
 #ifdef TTSWEEP_COL_PROFILE
         if (ip == P.NI - 1 && jp == P.NJ - 1 && s == 0 && e < 64 && lane == 0) g_col_sweep_time[e] = col_clock();
+        if (s == 6 && e >= 14 && e <= 16 && ip + jp < 512 && lane == 0) atomicMax((unsigned long long *)&g_col_level_time[e - 14][ip + jp], (unsigned long long)col_clock());
 #endif
         if (ip == P.NI - 1 && jp == P.NJ - 1 && anyimp == 0u && lane == 0) {
             // the sweep's last column - every column is upwind of it, and has finished its tiles -: no tile of the start
@@ -939,9 +970,10 @@ hipError_t launch_column_init(const ColumnSolve &P, const StartDesc *starts, boo
 // one: when only z flips (or nothing) it starts at the same corner, two levels behind; when x or y flips it starts at a
 // corner the sweep before passes HALF-WAY through - it lags (NI + NJ) / 2 levels, and in the sparse sweeps of a solve,
 // which are nothing but latency from level to level, that lag is the sweep's whole cost; x and y together: a whole
-// traversal.  The order along z is the column's own business, so z is the axis to flip most often - and in a velocity
-// model that changes mostly with depth the rays turn in z: the z-fastest sequences also converge in less work
-// (profiles/r05_col_sweep_order.txt: six-FS 1024x1024x512 x 14, 4.37 -> 3.13 grid sweeps per start, 120.7 -> 92 ms).
+// traversal.  The order along z is the column's own business.  What matters most, though, is the work: a start's
+// first sweeps should run into its largest octants (profiles/r05_col_sweep_order.txt: six-FS 1024x1024x512 x 14, from
+// 4.37 to 2.86 grid sweeps of due tiles per start and from 116 to 88 ms with the x-fastest cyclic code begun at the
+// corner nearest to each start; the z-fastest codes from the same corner: 2.95 - 3.15, 86 - 92 ms).
 //   which % 7: the sequence as seen from the corner (0, 0, 0);
 //   which / 7 % 3: the corner each start's first sweep begins at - 0: (0, 0, 0) for every start, 1: the corner NEAREST
 //     to the start (its first sweeps run into the largest octants), 2: the farthest;
