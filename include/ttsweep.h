@@ -168,8 +168,11 @@ typedef struct ttsweep_ctx ttsweep_ctx;
                                          of the solve */
 
 #define TTSWEEP_OPT_TILE_ORDER 24     /* schedule only, never the result (TILE kernel, one launch per solve): which
-                                         sequence of the eight orderings (+-x, +-y, +-z) successive sweeps follow -
-                                         0 .. 6, see column_order_sequence() in csrc/ttsweep_column.hip */
+                                         sequence of the eight orderings (+-x, +-y, +-z) the sweeps of each start follow:
+                                         table (0 .. 9) + 10 x the corner the first sweep begins at (0: the grid's origin,
+                                         1: the corner nearest to the start, 2: the farthest) + 100 x which axis plays
+                                         which role of the table (0 .. 4) - column_order_sequence() in
+                                         csrc/ttsweep_column.hip.  Default 111 (0: the sequence of rounds 3 - 5) */
 
 #define TTSWEEP_KERNEL_AUTO       0
 #define TTSWEEP_KERNEL_CELL       1   /* one thread per cell, star from global memory */

@@ -314,8 +314,8 @@ int ttsweep_set_option(ttsweep_ctx *ctx, int key, long long value)
         return 0;
     case TTSWEEP_OPT_TILE_IN_PLACE: ctx->col_in_place_off = value == 0; return 0;
     case TTSWEEP_OPT_TILE_ORDER:
-        if (value < 0 || value >= ttsweep::COL_ORDER_CHOICES)
-            return set_error("sweep order must be 0 .. %d", (int)ttsweep::COL_ORDER_CHOICES - 1);
+        if (value < 0 || value > 999 || !ttsweep::column_order_valid((int)value))
+            return set_error("sweep order: table 0 .. %d + 10 x first corner 0 .. 2 + 100 x axis roles 0 .. 4", (int)ttsweep::COL_ORDER_SEQUENCES - 1);
         ctx->col_order = (int)value;
         return 0;
     case TTSWEEP_OPT_ASYNC_INUNIT:

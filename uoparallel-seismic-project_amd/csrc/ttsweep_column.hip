@@ -974,12 +974,14 @@ hipError_t launch_column_init(const ColumnSolve &P, const StartDesc *starts, boo
 // first sweeps should run into its largest octants (profiles/r05_col_sweep_order.txt: six-FS 1024x1024x512 x 14, from
 // 4.37 to 2.86 grid sweeps of due tiles per start and from 116 to 88 ms with the x-fastest cyclic code begun at the
 // corner nearest to each start; the z-fastest codes from the same corner: 2.95 - 3.15, 86 - 92 ms).
-//   which % 7: the sequence as seen from the corner (0, 0, 0);
-//   which / 7 % 3: the corner each start's first sweep begins at - 0: (0, 0, 0) for every start, 1: the corner NEAREST
+//   `which` is read as three decimal digits.  The last one: the table - the sequence as seen from the corner (0, 0, 0);
+//   the tens: the corner each start's first sweep begins at - 0: (0, 0, 0) for every start, 1: the corner NEAREST
 //     to the start (its first sweeps run into the largest octants), 2: the farthest;
-//   which / 21: 0 - x, y, z as the table says; 1 - per start, the lateral axis along which the start lies nearer to
+//   the hundreds: 0 - x, y, z as the table says; 1 - per start, the lateral axis along which the start lies nearer to
 //     the middle of the grid plays the table's x, 2 - the other one; 3 - the three axes by how near to the middle the
 //     start lies along them play x, y, z (the nearest: x), 4 - the other way round.
+bool column_order_valid(int which) { return which >= 0 && which % 10 < COL_ORDER_SEQUENCES && which / 10 % 10 < 3 && which / 100 < 5; }
+
 void column_order_sequence(int which, const int (&n)[3], const int (&at)[3], unsigned long long *seq)
 {
     static const unsigned char table[COL_ORDER_SEQUENCES][16] = {
@@ -997,9 +999,14 @@ void column_order_sequence(int which, const int (&n)[3], const int (&at)[3], uns
         {0, 4, 1, 5, 3, 7, 2, 6, 0, 4, 1, 5, 3, 7, 2, 6},
         // 6: as 5, pairs in the other order
         {0, 4, 5, 1, 7, 3, 2, 6, 0, 4, 5, 1, 7, 3, 2, 6},
+        // 7 - 9: the first eight sweeps as 1, the next eight with z fastest (the late sweeps of a solve are chains of
+        // single tiles across the grid: a sweep that flips only z rides on the one before) - then x, then y, mixed
+        {0, 1, 3, 2, 6, 7, 5, 4, 0, 4, 5, 1, 3, 7, 6, 2},
+        {0, 1, 3, 2, 6, 7, 5, 4, 0, 4, 6, 2, 3, 7, 5, 1},
+        {0, 1, 3, 2, 6, 7, 5, 4, 0, 4, 5, 7, 6, 2, 3, 1},
     };
-    if (which < 0 || which >= COL_ORDER_CHOICES) which = 0;
-    const int base = which % COL_ORDER_SEQUENCES, first = which / COL_ORDER_SEQUENCES % 3, axes = which / (3 * COL_ORDER_SEQUENCES);
+    if (!column_order_valid(which)) which = 0;
+    const int base = which % 10, first = which / 10 % 10, axes = which / 100;
     unsigned x = 0;
     for (int d = 0; d < 3 && first; d++)
         if ((2 * at[d] >= n[d]) == (first == 1)) x |= 1u << d;

@@ -147,7 +147,7 @@ struct ttsweep_ctx {
     float **d_col_tptr = nullptr, **h_col_tptr = nullptr;  // the starts' travel-time volumes (h_: pinned)
     unsigned long long *d_col_ordseq = nullptr, *h_col_ordseq = nullptr;   // the starts' sequences of orderings (sized with tptr)
     int col_cap_tptr = 0;
-    int col_order = 29;                     // TTSWEEP_OPT_TILE_ORDER: which sequence of the eight orderings each start's sweeps follow (column_order_sequence)
+    int col_order = 111;                    // TTSWEEP_OPT_TILE_ORDER: which sequence of the eight orderings each start's sweeps follow (column_order_sequence)
     bool col_in_place_off = false;          // TTSWEEP_OPT_TILE_IN_PLACE = 0: always relax in the library's padded volumes
     int col_cap_starts = 0;                 // starts the buffers above were sized for
     int col_seq_key[3] = {0, 0, 0};         // NI, NJ, sequences the table on the device was made for

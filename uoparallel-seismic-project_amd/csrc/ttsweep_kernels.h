@@ -121,7 +121,8 @@ hipError_t launch_column_init(const ColumnSolve &P, const StartDesc *starts, boo
 hipError_t column_solve_wgs_per_cu(int *wgs);   // workgroups a CU holds (and the LDS opt-in)
 int column_solve_wg_waves();                    // wavefronts (columns in flight) of one workgroup
 // the sequence of orderings the sweeps of a start follow (TTSWEEP_OPT_TILE_ORDER; n: the grid, at: the start, device axes)
-constexpr int COL_ORDER_SEQUENCES = 7, COL_ORDER_CHOICES = 15 * COL_ORDER_SEQUENCES;
+constexpr int COL_ORDER_SEQUENCES = 10;
+bool column_order_valid(int which);        // table + 10 x first corner + 100 x axis roles
 void column_order_sequence(int which, const int (&n)[3], const int (&at)[3], unsigned long long *seq);
 // the whole solve: the wavefronts of `nblocks` resident workgroups claim columns until every start is at rest
 hipError_t launch_column_solve(const ColumnSolve &P, int nblocks, hipStream_t st);
