@@ -221,8 +221,15 @@ static int solve_async_strip(ttsweep_ctx *ctx, int nstart, std::vector<int> &swe
     const int cap = 1 << 14;
     as.cap_mask = cap - 1;
     const int workers = std::max((nblocks - as.nrings) / as.nrings, 1);
-    as.low = ctx->async_low > 0 ? ctx->async_low : std::max(workers / 2, 8);
-    as.high = ctx->async_high > 0 ? ctx->async_high : 2 * workers;
+    // fill marks of a ring: half / twice its workers where the units of a ring are a few thousand (241 x 241 x 51 x 24:
+    // 5.8 k per ring - fuller rings relax MORE there: 27.9 / 28.3 / 29.3 / 31.1 ms with 126 / 256 / 512 / 1024); on the
+    // grids that leave the caches the front is thousands of units wide and a fuller ring is less work and less time
+    // (512 x 512 x 256 x 8, 33 k units per ring: 288 / 276 / 273 / 269 / 264 / 258 ms with 126 / 256 / 512 / 1024 / 2048 /
+    // 4096; 1024 x 1024 x 512 x 14: 3.95 -> 3.83 s with 1024) - profiles/r05_big_grid_ring_marks.txt
+    const long long units_per_ring = (long long)nstart * nunits / std::max(as.nrings, 1);
+    const int high0 = units_per_ring >= 16384 ? std::min(4096, cap / 4) : 2 * workers;
+    as.low = ctx->async_low > 0 ? ctx->async_low : std::max(units_per_ring >= 16384 ? high0 / 4 : workers / 2, 8);
+    as.high = ctx->async_high > 0 ? ctx->async_high : high0;
     as.high = std::max(as.high, as.low + 1);
     as.special_every = ctx->async_special_every;
     // lists
