@@ -53,7 +53,8 @@ other = {"g512_818": line("g512_818.json"), "g1024_818": line("g1024_818.json"),
          "what": "bench.py --no-cpu --no-host --no-hbm-regime (traffic measured live) --grid 512,512,256 --starts 111 --nstarts 8 --steps 2 --warmup 1 / "
                  "--grid 1024,1024,512 --starts 111 --nstarts 14 --steps 1 --warmup 1, 818-FS (tools/exp/r5final.sh c)"}
 json.dump(other, open(os.path.join(P, "r05_other_config_lines.json"), "w"), indent=1)
-json.dump(line("cpu_b2_line.json"), open(os.path.join(P, "r05_cpu_b2_line.json"), "w"), indent=1)
+if os.path.exists(os.path.join(O, "cpu_b2_line.json")):       # (part d of r5final.sh: 190 s of CPU; not in every regeneration)
+    json.dump(line("cpu_b2_line.json"), open(os.path.join(P, "r05_cpu_b2_line.json"), "w"), indent=1)
 
 
 def counters(name):

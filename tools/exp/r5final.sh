@@ -2,7 +2,7 @@
 # Regenerates the round-5 artefacts under profiles/ (run on the GPU box: gpurun -- 'bash tools/exp/r5final.sh [part]').
 # Everything goes to gpurun_out/r5final/; tools/exp/collect_r5.py copies what is wanted into profiles/ afterwards.
 # Builds wanted in gpurun_exp/: asyncstats.so (-DTTSWEEP_ASYNC_STATS), colprof.so (-DTTSWEEP_COL_PROFILE), stripprof.so (-DTTSWEEP_PROFILE).
-# part: a (bench line, kernel stats, small shards, phases), b (HBM regime, column profile, counters), c (other configs, CPU leg B2); default all
+# part: a (bench line, kernel stats, small shards, phases), b (HBM regime, column profile, counters), c (other configs), d (CPU leg B2, 190 s); default a, b, c
 cd "${GRAFT_REPO_ROOT:-.}"
 export TMPDIR=/tmp
 part=${1:-abc}
@@ -48,7 +48,7 @@ echo "== where the column wavefronts' time goes (-DTTSWEEP_COL_PROFILE build)"
 TTSWEEP_LIB=gpurun_exp/colprof.so timeout -k 10 400 python tools/exp/col_probe.py 1024,1024,512 14 2 1 > $O/col_profile.txt 2>&1; echo "rc=$?"
 echo "== starts resident per launch"
 : > $O/col_batch.txt
-for n in 7 14 28 56; do timeout -k 10 400 python tools/exp/col_probe.py 1024,1024,512 $n 2 1 2>&1 | grep "mode 1 (" | tail -1 >> $O/col_batch.txt; done
+for n in 7 14 28 56; do timeout -k 10 400 python tools/exp/col_probe.py 1024,1024,512 $n 2 1 2>&1 | grep "^mode 1 order" | tail -1 >> $O/col_batch.txt; done
 echo "== SQ counters of the unit kernel and of the column kernel"
 bash tools/exp/pmc.sh r5sq1 "--steps 2 --warmup 1 --no-hbm-regime" sweep_units SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CU_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_SALU > $O/pmc_sq1.txt 2>&1
 bash tools/exp/pmc.sh r5sq2 "--steps 2 --warmup 1 --no-hbm-regime" sweep_units SQ_ACTIVE_INST_VALU SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_INSTS_SMEM SQ_WAIT_INST_LDS SQ_ACTIVE_INST_SCA > $O/pmc_sq2.txt 2>&1
@@ -62,6 +62,8 @@ echo "== the other configurations (818-FS) with HBM-side traffic"
 B2="python bench.py --no-cpu --no-host --no-hbm-regime"
 $B2 --steps 2 --warmup 1 --grid 512,512,256 --starts 111 --nstarts 8 > $O/g512_818.json 2> $O/g512_818.err; echo "g512 rc $?"
 timeout -k 10 500 $B2 --steps 1 --warmup 1 --grid 1024,1024,512 --starts 111 --nstarts 14 > $O/g1024_818.json 2> $O/g1024_818.err; echo "g1024 rc $?"
+fi
+if [[ $part == *d* ]]; then
 echo "== BASELINE.md leg B2 in a bench line (start-1 to convergence on one host core: about 190 s)"
 timeout -k 10 900 $B --steps 3 --warmup 1 --nstarts 1 --cpu-b2 > $O/cpu_b2_line.json 2> $O/cpu_b2.err; echo "b2 rc $?"
 fi
