@@ -22,6 +22,7 @@ orders = [int(x) for x in os.environ.get("ORDERS", "-1").split(",")]     # (-1: 
 for mode, order in [(m, o) for m in modes for o in (orders if m else orders[:1])]:
     with P.TravelTimeSolver(shape, fs) as sol:
         if order >= 0: sol.set_option(P.OPT_TILE_ORDER, order)
+        if os.environ.get("QUEUES"): sol.set_option(P.OPT_QUEUES, int(os.environ["QUEUES"]))      # claim sequences
         sol.set_option(P.OPT_ASYNC, 1 if mode == 2 else mode)     # (mode 2: columns, in the library's padded volumes)
         if mode == 2:
             sol.set_option(P.OPT_TILE_IN_PLACE, 0)
