@@ -304,27 +304,26 @@ __device__ __forceinline__ void col_work_add(const ColumnSolve &P, ColWork &w, i
     }
 }
 
-// Lanes 0 .. 4 poll one progress word each (pa; !valid: nothing to wait for) until its key reaches `need`.
-// false: the solve is over for this column (the start is at rest, the solve has failed or ended).
-// first_done: the start's "at rest" word is read with the first round of the poll (lane 7) - a column claimed for a
-// start that has come to rest leaves here, without a round trip of its own in front of the poll.
+// Lanes 0 .. 6 poll one progress word each (pa; !valid: nothing to wait for) until its key reaches `need`.
+// false: the solve is over for this column (the start is at rest, the solve has failed or ended): the launch's status
+// word and the start's "at rest" word ride along in lanes 62 and 63 of EVERY round - a column claimed for a start that
+// has come to rest leaves with the first one, and no round has round trips of its own for them (round 4: three
+// dependent loads every fourth round).
 __device__ __forceinline__ bool col_poll(const ColumnSolve &P, const unsigned long long *pa, bool valid, unsigned need,
-                                         unsigned long long &pv, int s, long long deadline, bool first_done = false)
+                                         unsigned long long &pv, int s, long long deadline)
 {
+    const int lane = threadIdx.x & 63;
     for (unsigned spin = 0;; spin++) {
-        pv = valid ? cld64(pa) : ~0ull;
-        if (first_done && spin == 0u) {
-            unsigned dn = 0u;
-            if ((threadIdx.x & 63) == 7) dn = cld32(reinterpret_cast<const unsigned *>(P.done + s));
-            if (__ballot(dn != 0u) != 0ull) return false;
-        }
+        unsigned long long x = ~0ull;
+        if (valid) x = cld64(pa);
+        else if (lane == 62) x = cld32(P.status);
+        else if (lane == 63) x = cld32(reinterpret_cast<const unsigned *>(P.done + s));
+        pv = valid ? x : ~0ull;
+        if (__ballot(!valid && ((lane == 62 && (unsigned)x != (unsigned)COL_RUNNING) || (lane == 63 && (unsigned)x != 0u))) != 0ull)
+            return false;
         const bool ok = !valid || (unsigned)(pv >> 32) >= need;
         if (__ballot(!ok) == 0ull) return true;
-        if ((spin & 3u) == 3u) {
-            if (cld32(P.status) != COL_RUNNING) return false;
-            if (cld32(reinterpret_cast<const unsigned *>(P.done + s)) != 0u) return false;
-            if (col_clock() > deadline) { col_fail(P, COL_ERR_TIMEOUT); return false; }
-        }
+        if ((spin & 3u) == 3u && col_clock() > deadline) { col_fail(P, COL_ERR_TIMEOUT); return false; }
         __builtin_amdgcn_s_sleep(4);
     }
 }
@@ -591,12 +590,14 @@ column_solve_kernel(const ColumnSolve P)
         const unsigned long long *const pa = prog + ncolumn;      // (lanes 1, 2: the upwind columns' words of THIS sweep)
         unsigned long long pv = 0;
         // nobody is still in sweep e - 1 around this column (lanes 0 .. 4: the five words of sweep e - 1); the same round
-        // brings the upwind columns' words of this sweep (lanes 5, 6: nothing to wait for) and the start's word (lane 7)
+        // brings the upwind columns' words of this sweep (lanes 5, 6: nothing to wait for) and the status words (lanes 62, 63)
         const long long pt1 = CPROF_NOW();
         (void)pt1;
         CPROF_ADD(1, pt1 - pt0);
-        if (!col_poll(P, lane < 5 ? prog_prev + ncolumn : pa, valid && lane < 7, lane < 5 ? col_key(e - 1, 0xff) : 0u, pv, s, deadline,
-                      /*first_done=*/true)) { CPROF_ADD(9, 1); continue; }
+        if (!col_poll(P, lane < 5 ? prog_prev + ncolumn : pa, valid && lane < 7, lane < 5 ? col_key(e - 1, 0xff) : 0u, pv, s, deadline)) {
+            CPROF_ADD(9, 1);
+            continue;
+        }
         long long pt2 = CPROF_NOW();
         (void)pt2;
         CPROF_ADD(2, pt2 - pt1);
