@@ -172,7 +172,10 @@ typedef struct ttsweep_ctx ttsweep_ctx;
                                          table (0 .. 9) + 10 x the corner the first sweep begins at (0: the grid's origin,
                                          1: the corner nearest to the start, 2: the farthest) + 100 x which axis plays
                                          which role of the table (0 .. 4) - column_order_sequence() in
-                                         csrc/ttsweep_column.hip.  Default 111 (0: the sequence of rounds 3 - 5) */
+                                         csrc/ttsweep_column.hip (0: the sequence of rounds 3 - 4).  -1 (default): per start, by where
+                                         the start lies in the velocity profile of its vertical line (115: z flips with
+                                         every sweep - sources at the slow end of a medium that gets faster with depth;
+                                         111 for a start at the fast end) - column_order_default() */
 
 #define TTSWEEP_KERNEL_AUTO       0
 #define TTSWEEP_KERNEL_CELL       1   /* one thread per cell, star from global memory */

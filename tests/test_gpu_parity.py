@@ -1045,7 +1045,7 @@ def test_column_driver_with_fewer_claim_sequences(P, oracle, queues):
             assert_bit_equal(tt[s].cpu().numpy(), want[s], f"{queues} sequences, start {starts[s]}")
 
 
-@pytest.mark.parametrize("order", [0, 1, 2, 3, 5, 11, 24, 111, 114, 204, 311, 412, 429, 117, 18, 119])
+@pytest.mark.parametrize("order", [-1, 0, 1, 2, 3, 5, 11, 24, 111, 114, 115, 204, 311, 412, 429, 117, 18, 119])
 def test_column_driver_sequences_of_orderings(P, oracle, order):
     """TTSWEEP_OPT_TILE_ORDER: the sequence of the eight orderings each start's sweeps follow (which table, from which
     corner, which axis in which role - column_order_sequence) changes how many sweeps and how much work a solve is,
@@ -1056,6 +1056,8 @@ def test_column_driver_sequences_of_orderings(P, oracle, order):
     for shape, seed in (((70, 33, 96), 71), ((24, 41, 160), 72)):
         rng = np.random.default_rng(seed)
         v = rng.uniform(0.1, 0.5, size=shape).astype(np.float32)
+        if order < 0:       # the default looks at the velocity profile of a start's vertical line: give it one (faster with depth)
+            v = (v * 0.05 + np.linspace(0.15, 0.4, shape[2], dtype=np.float32)[None, None, :]).astype(np.float32)
         starts = np.array([[0, 0, 0], [shape[0] - 1, shape[1] - 1, shape[2] - 1], [shape[0] // 2, 3, shape[2] - 2],
                            [shape[0] // 3, shape[1] // 2, shape[2] // 2], [shape[0] - 2, 1, 40]], dtype=np.int32)
         want = [oracle.converge(v, oracle.make_star(six), st, order=1)[0] for st in starts]

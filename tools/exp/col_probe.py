@@ -16,6 +16,8 @@ dev = torch.device("cuda:0")
 v = P.inputs.velocity_model_device(*shape, 20160507, dev)
 fs = P.inputs.make_fs(P.inputs.read_triples(P.inputs.star_path("six")))
 starts = P.inputs.scaled_starts(P.inputs.read_triples(P.inputs.starts_path("111")), *shape)[:nstart]
+if os.environ.get("START_K"):     # the starts at another depth (fraction of nz, e.g. 0.5) instead of on the face k = nz - 1
+    starts = starts.copy(); starts[:, 2] = int(float(os.environ["START_K"]) * (shape[2] - 1))
 cells = shape[0] * shape[1] * shape[2]
 digest = {}
 orders = [int(x) for x in os.environ.get("ORDERS", "-1").split(",")]     # (-1: the library's default)

@@ -201,6 +201,8 @@ void ttsweep_destroy(ttsweep_ctx *ctx)
     (void)hipFree(ctx->d_col_status);
     (void)hipFree(ctx->d_col_done);
     (void)hipFree(ctx->d_col_ordseq);
+    (void)hipFree(ctx->d_col_line);
+    if (ctx->h_col_line) (void)hipHostFree(ctx->h_col_line);
     if (ctx->h_col_ordseq) (void)hipHostFree(ctx->h_col_ordseq);
     (void)hipFree(ctx->d_col_seqtab);
     (void)hipFree(ctx->d_col_tptr);
@@ -314,8 +316,8 @@ int ttsweep_set_option(ttsweep_ctx *ctx, int key, long long value)
         return 0;
     case TTSWEEP_OPT_TILE_IN_PLACE: ctx->col_in_place_off = value == 0; return 0;
     case TTSWEEP_OPT_TILE_ORDER:
-        if (value < 0 || value > 999 || !ttsweep::column_order_valid((int)value))
-            return set_error("sweep order: table 0 .. %d + 10 x first corner 0 .. 2 + 100 x axis roles 0 .. 4", (int)ttsweep::COL_ORDER_SEQUENCES - 1);
+        if (value != -1 && (value < 0 || value > 999 || !ttsweep::column_order_valid((int)value)))
+            return set_error("sweep order: -1 (by the model) or table 0 .. %d + 10 x first corner 0 .. 2 + 100 x axis roles 0 .. 4", (int)ttsweep::COL_ORDER_SEQUENCES - 1);
         ctx->col_order = (int)value;
         return 0;
     case TTSWEEP_OPT_ASYNC_INUNIT:

@@ -936,6 +936,55 @@ column_init_kernel(ColumnSolve P, const StartDesc *__restrict__ starts, int from
     if (t == 0) { P.status[0] = COL_RUNNING; P.status[1] = (unsigned)P.nstart; }
 }
 
+// ---------------------------------------------------------------------------
+// what the default choice of a start's sequence of orderings looks at: the velocity values along the vertical line
+// through the start - the value at the start, the least and the largest of the line (out[3 s ..])
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(64)
+column_line_kernel(const float *__restrict__ v, DevLayout L, const StartDesc *__restrict__ starts, float *__restrict__ out)
+{
+    const StartDesc &sd = starts[blockIdx.x];
+    const float *const row = v + dev_index(L, sd.sa, sd.sb, 0);
+    float lo = INFINITY, hi = -INFINITY;
+    for (int c = threadIdx.x; c < L.n[2]; c += 64) {
+        const float x = row[c];
+        lo = fminf(lo, x);
+        hi = fmaxf(hi, x);
+    }
+    for (int off = 32; off; off >>= 1) {
+        lo = fminf(lo, __shfl_xor(lo, off));
+        hi = fmaxf(hi, __shfl_xor(hi, off));
+    }
+    if (threadIdx.x == 0) {
+        out[3 * blockIdx.x] = row[sd.sc];
+        out[3 * blockIdx.x + 1] = lo;
+        out[3 * blockIdx.x + 2] = hi;
+    }
+}
+
+hipError_t launch_column_line(const float *v, const DevLayout &L, const StartDesc *starts, int nstart, float *out, hipStream_t st)
+{
+    hipLaunchKernelGGL(column_line_kernel, dim3((unsigned)nstart), dim3(64), 0, st, v, L, starts, out);
+    return hipGetLastError();
+}
+
+// The default (TTSWEEP_OPT_TILE_ORDER = -1): by where the start lies in the velocity profile of its vertical line.
+// The volume holds delay per distance (the reference adds h (v + v') along an edge): a start where that is LARGE - a
+// source at the surface of a medium that gets faster with depth, the reference's own data - sends rays that dive and
+// come back, and each lateral quadrant wants its downward and its upward ordering next to each other (table 5: z flips
+// with every sweep); a start at the FAST end of its line is served better by the x-fastest cyclic code (table 1), and so
+// is a start at the slow end of a grid that is at least as deep as it is wide.  Measured on nine geometries and four
+// depths of the starts (profiles/r05_col_sweep_order.txt, second half): 1024 x 1024 x 512 x 14 from the surface 87 -> 78
+// ms, 1024 x 1024 x 256: 87 -> 58, 241 x 241 x 51 x 24: 5.8 -> 5.0; the cubes keep table 1.
+int column_order_default(const int (&n)[3], float at_start, float least, float largest)
+{
+    const float range = largest - least;
+    const float f = range > 0.f ? (at_start - least) / range : 0.5f;       // 0: the fast end of the line, 1: the slow end
+    if (f < 0.15f) return 111;
+    if (f > 0.85f && n[2] >= std::max(n[0], n[1])) return 111;
+    return 115;
+}
+
 int column_solve_wg_waves() { return CWG; }
 
 // The opt-in to more than 64 KB of dynamic LDS belongs to the CURRENT device: every context (one per device in

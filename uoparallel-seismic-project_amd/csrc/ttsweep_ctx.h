@@ -145,9 +145,10 @@ struct ttsweep_ctx {
     unsigned *d_col_due = nullptr, *d_col_status = nullptr, *h_col_status = nullptr;   // (h_: pinned)
     int *d_col_done = nullptr, *h_col_done = nullptr, *d_col_seqtab = nullptr;
     float **d_col_tptr = nullptr, **h_col_tptr = nullptr;  // the starts' travel-time volumes (h_: pinned)
+    float *d_col_line = nullptr, *h_col_line = nullptr;     // per start: velocity at the start, least / largest of its vertical line (sized with tptr)
     unsigned long long *d_col_ordseq = nullptr, *h_col_ordseq = nullptr;   // the starts' sequences of orderings (sized with tptr)
     int col_cap_tptr = 0;
-    int col_order = 111;                    // TTSWEEP_OPT_TILE_ORDER: which sequence of the eight orderings each start's sweeps follow (column_order_sequence)
+    int col_order = -1;                     // TTSWEEP_OPT_TILE_ORDER: which sequence of the eight orderings each start's sweeps follow (column_order_sequence)
     bool col_in_place_off = false;          // TTSWEEP_OPT_TILE_IN_PLACE = 0: always relax in the library's padded volumes
     int col_cap_starts = 0;                 // starts the buffers above were sized for
     int col_seq_key[3] = {0, 0, 0};         // NI, NJ, sequences the table on the device was made for

@@ -521,6 +521,9 @@ static int solve_column(ttsweep_ctx *ctx, int nstart, bool from_box, float *cons
         if (ctx->h_col_tptr) HIPCHK(hipHostFree(ctx->h_col_tptr));
         if (ctx->d_col_ordseq) HIPCHK(hipFree(ctx->d_col_ordseq));
         if (ctx->h_col_ordseq) HIPCHK(hipHostFree(ctx->h_col_ordseq));
+        if (ctx->d_col_line) HIPCHK(hipFree(ctx->d_col_line));
+        if (ctx->h_col_line) HIPCHK(hipHostFree(ctx->h_col_line));
+        ctx->d_col_line = nullptr; ctx->h_col_line = nullptr;
         ctx->d_col_tptr = nullptr; ctx->h_col_tptr = nullptr;
         ctx->d_col_ordseq = nullptr; ctx->h_col_ordseq = nullptr;
         ctx->col_cap_tptr = 0;
@@ -528,6 +531,8 @@ static int solve_column(ttsweep_ctx *ctx, int nstart, bool from_box, float *cons
         HIPCHK(hipHostMalloc((void **)&ctx->h_col_tptr, (size_t)nstart * sizeof(float *)));
         HIPCHK(hipMalloc((void **)&ctx->d_col_ordseq, (size_t)nstart * sizeof(unsigned long long)));
         HIPCHK(hipHostMalloc((void **)&ctx->h_col_ordseq, (size_t)nstart * sizeof(unsigned long long)));
+        HIPCHK(hipMalloc((void **)&ctx->d_col_line, (size_t)nstart * 3 * sizeof(float)));
+        HIPCHK(hipHostMalloc((void **)&ctx->h_col_line, (size_t)nstart * 3 * sizeof(float)));
         ctx->col_cap_tptr = nstart;
     }
     for (int s = 0; s < nstart; s++) ctx->h_col_tptr[s] = in_place ? tt_dev[s] : ctx->d_T + (size_t)s * L.cells;
@@ -565,10 +570,17 @@ static int solve_column(ttsweep_ctx *ctx, int nstart, bool from_box, float *cons
     static const int order[6] = {0, 1, 2, 3, 4, 5};     // (tile_star_is_six: x-, y-, z-, z+, y+, x+)
     for (int e = 0; e < 6; e++) C.h[e] = ctx->tile_ent[order[e]].h;
     C.max_sweeps = (int)std::min<long long>(ctx->max_sweeps, COL_MAX_SWEEPS - 2);
+    if (ctx->col_order < 0) {       // the default: chosen per start from the velocity profile of its vertical line
+        HIPCHK(launch_column_line(ctx->d_v, L, ctx->d_starts, nstart, ctx->d_col_line, ctx->stream));
+        HIPCHK(hipMemcpyAsync(ctx->h_col_line, ctx->d_col_line, (size_t)nstart * 3 * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(hipStreamSynchronize(ctx->stream));
+    }
     for (int s = 0; s < nstart; s++) {
         const StartDesc &sd = ctx->h_starts[s];
         const int at[3] = {sd.sa, sd.sb, sd.sc}, nn[3] = {L.n[0], L.n[1], L.n[2]};
-        column_order_sequence(ctx->col_order, nn, at, &ctx->h_col_ordseq[s]);
+        const int which = ctx->col_order >= 0 ? ctx->col_order
+                        : column_order_default(nn, ctx->h_col_line[3 * s], ctx->h_col_line[3 * s + 1], ctx->h_col_line[3 * s + 2]);
+        column_order_sequence(which, nn, at, &ctx->h_col_ordseq[s]);
 #ifdef TTSWEEP_DEBUG_ENV
         if (const char *q = getenv("TTSWEEP_COL_ORDSEQ")) ctx->h_col_ordseq[s] = strtoull(q, nullptr, 16);   // (sweep 1: the lowest nibble)
 #endif

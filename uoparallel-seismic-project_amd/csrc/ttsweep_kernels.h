@@ -122,6 +122,8 @@ hipError_t column_solve_wgs_per_cu(int *wgs);   // workgroups a CU holds (and th
 int column_solve_wg_waves();                    // wavefronts (columns in flight) of one workgroup
 // the sequence of orderings the sweeps of a start follow (TTSWEEP_OPT_TILE_ORDER; n: the grid, at: the start, device axes)
 constexpr int COL_ORDER_SEQUENCES = 10;
+hipError_t launch_column_line(const float *v, const DevLayout &L, const StartDesc *starts, int nstart, float *out, hipStream_t st);
+int column_order_default(const int (&n)[3], float at_start, float least, float largest);   // the choice for one start (-1: by the model)
 bool column_order_valid(int which);        // table + 10 x first corner + 100 x axis roles
 void column_order_sequence(int which, const int (&n)[3], const int (&at)[3], unsigned long long *seq);
 // the whole solve: the wavefronts of `nblocks` resident workgroups claim columns until every start is at rest
