@@ -49,10 +49,11 @@ open(os.path.join(P, "r05_strip_phases.txt"), "w").write(
 open(os.path.join(P, "r05_col_batch_size.txt"), "w").write(
     "Column kernel, six-FS, 1024x1024x512: starts resident per launch (tools/exp/col_probe.py 1024,1024,512 N 2 1, second solve; 8 TB/s roof)\n\n"
     + text("col_batch.txt"))
-other = {"g512_818": line("g512_818.json"), "g1024_818": line("g1024_818.json"),
+if os.path.exists(os.path.join(O, "g512_818.json")):     # (part c)
+  other = {"g512_818": line("g512_818.json"), "g1024_818": line("g1024_818.json"),
          "what": "bench.py --no-cpu --no-host --no-hbm-regime (traffic measured live) --grid 512,512,256 --starts 111 --nstarts 8 --steps 2 --warmup 1 / "
                  "--grid 1024,1024,512 --starts 111 --nstarts 14 --steps 1 --warmup 1, 818-FS (tools/exp/r5final.sh c)"}
-json.dump(other, open(os.path.join(P, "r05_other_config_lines.json"), "w"), indent=1)
+  json.dump(other, open(os.path.join(P, "r05_other_config_lines.json"), "w"), indent=1)
 if os.path.exists(os.path.join(O, "cpu_b2_line.json")):       # (part d of r5final.sh: 190 s of CPU; not in every regeneration)
     json.dump(line("cpu_b2_line.json"), open(os.path.join(P, "r05_cpu_b2_line.json"), "w"), indent=1)
 
