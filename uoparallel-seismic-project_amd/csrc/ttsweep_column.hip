@@ -1049,11 +1049,13 @@ void column_order_sequence(int which, const int (&n)[3], const int (&at)[3], uns
         {0, 4, 1, 5, 3, 7, 2, 6, 0, 4, 1, 5, 3, 7, 2, 6},
         // 6: as 5, pairs in the other order
         {0, 4, 5, 1, 7, 3, 2, 6, 0, 4, 5, 1, 7, 3, 2, 6},
-        // 7 - 9: the first eight sweeps as 1, the next eight with z fastest (the late sweeps of a solve are chains of
-        // single tiles across the grid: a sweep that flips only z rides on the one before) - then x, then y, mixed
-        {0, 1, 3, 2, 6, 7, 5, 4, 0, 4, 5, 1, 3, 7, 6, 2},
+        // 7: as 5, the quadrants of the second eight sweeps in the opposite order
+        {0, 4, 1, 5, 3, 7, 2, 6, 2, 6, 3, 7, 1, 5, 0, 4},
+        // 8: the first eight sweeps as 1, the next eight with z fastest (the late sweeps of a solve are chains of
+        // single tiles across the grid: a sweep that flips only z rides on the one before)
         {0, 1, 3, 2, 6, 7, 5, 4, 0, 4, 6, 2, 3, 7, 5, 1},
-        {0, 1, 3, 2, 6, 7, 5, 4, 0, 4, 5, 7, 6, 2, 3, 1},
+        // 9: two quadrants down, the same two up
+        {0, 1, 5, 4, 2, 3, 7, 6, 0, 1, 5, 4, 2, 3, 7, 6},
     };
     if (!column_order_valid(which)) which = 0;
     const int base = which % 10, first = which / 10 % 10, axes = which / 100;
